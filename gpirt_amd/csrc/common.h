@@ -1,0 +1,156 @@
+// Shared declarations of the gfx950 GPIRT library: error plumbing, the counter-based
+// generator, the ordinal-probit cell, padding rules and the kernel launch prototypes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/gpirt.h"
+
+namespace gpirt {
+
+// ---- padding ---------------------------------------------------------------------
+// Every dense operand is padded to multiples of TILE in both dimensions so that no MFMA
+// tile needs a bounds check.  Pad rows/columns of data matrices are zero; the pad block of
+// a kernel matrix is the identity, which keeps its Cholesky factor block-diagonal.
+constexpr int TILE = 128;
+inline int64_t pad_up(int64_t v, int64_t t = TILE) { return (v + t - 1) / t * t; }
+
+// ---- error plumbing ----------------------------------------------------------------
+void set_error(const char *fmt, ...);
+#define GP_HIP(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      gpirt::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                       __LINE__);                                                      \
+      return GPIRT_ERR_HIP;                                                            \
+    }                                                                                  \
+  } while (0)
+#define GP_TRY(expr)            \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != GPIRT_OK) return rc_; \
+  } while (0)
+
+// ---- stream tags of the generator (shared with the CPU oracle) -----------------------
+enum : uint32_t {
+  TAG_F_Z = 1, TAG_F_U = 2, TAG_P_Z = 3, TAG_P_U = 4, TAG_T_Z = 5, TAG_T_U = 6, TAG_INIT = 7
+};
+
+// ---- Philox4x32-10, counter = (index, unit, sweep, tag), key = seed -------------------
+__host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+__host__ __device__ inline double u53(uint32_t hi, uint32_t lo) {
+  return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6) + 0.5) *
+         (1.0 / 9007199254740992.0);
+}
+
+__host__ __device__ inline void rng_uniform_pair(uint64_t seed, uint32_t tag, uint32_t sweep,
+                                                 uint32_t unit, uint32_t q, double &u0,
+                                                 double &u1) {
+  uint32_t c[4] = {q, unit, sweep, tag};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  u0 = u53(c[0], c[1]);
+  u1 = u53(c[2], c[3]);
+}
+
+__host__ __device__ inline double rng_uniform_at(uint64_t seed, uint32_t tag, uint32_t sweep,
+                                                 uint32_t unit, uint32_t d) {
+  double a, b;
+  rng_uniform_pair(seed, tag, sweep, unit, d >> 1, a, b);
+  return (d & 1) ? b : a;
+}
+
+constexpr double kTwoPi = 6.283185307179586476925286766559;
+
+// Box-Muller on one Philox block: two standard normals.
+__host__ __device__ inline void rng_normal_pair(uint64_t seed, uint32_t tag, uint32_t sweep,
+                                                uint32_t unit, uint32_t q, double &z0,
+                                                double &z1) {
+  double a, b;
+  rng_uniform_pair(seed, tag, sweep, unit, q, a, b);
+  double r = sqrt(-2.0 * log(a));
+  double s, c;
+  sincos(kTwoPi * b, &s, &c);
+  z0 = r * c;
+  z1 = r * s;
+}
+
+__host__ __device__ inline double rng_normal_at(uint64_t seed, uint32_t tag, uint32_t sweep,
+                                                uint32_t unit, uint32_t d) {
+  double a, b;
+  rng_normal_pair(seed, tag, sweep, unit, d >> 1, a, b);
+  return (d & 1) ? b : a;
+}
+
+// ---- the ordinal-probit cell ----------------------------------------------------------
+// log( Phi(zhi) - Phi(zlo) ) for zlo < zhi, on the upper tails when both are positive
+// (log_like_fn.m:3-4 with the probit link of sigmoid_fn.m:4, ordinal form
+// gpirt-sythetic.R:159-167).  The floor keeps a vanished cell finite.
+constexpr double kInvSqrt2 = 0.70710678118654752440084436210485;
+constexpr double kPFloor = 1e-300;
+
+__host__ __device__ inline double ordinal_cell_z(double zlo, double zhi) {
+  double p;
+  if (zlo > 0.0)
+    p = 0.5 * erfc(zlo * kInvSqrt2) - 0.5 * erfc(zhi * kInvSqrt2);
+  else
+    p = 0.5 * erfc(-zhi * kInvSqrt2) - 0.5 * erfc(-zlo * kInvSqrt2);
+  if (!(p > kPFloor)) p = kPFloor;
+  return log(p);
+}
+
+// ---- wave-level sum (64 lanes) ----------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---- dense launchers (dense.hip) ---------------------------------------------------------
+struct GemmArgs {
+  const double *A; int64_t lda, strideA;
+  const double *B; int64_t ldb, strideB;
+  double *C;       int64_t ldc, strideC;
+  int M, N, K;       // multiples of TILE, TILE, 16
+  int batch;
+  double alpha, beta;
+  int lower_only;    // compute only tiles with row-block >= col-block (C square)
+  int k_trim;        // 1: A is lower-triangular => K range of row-block bi is [0,(bi+1)*TILE)
+                     // 2: A^T is used with A lower-triangular => K range is [bi*TILE, K)
+};
+// C = alpha * op(A) * op(B) + beta * C.
+//   AT = false: A(i,k) at A[i + lda*k];  AT = true: A(i,k) at A[k + lda*i]
+//   BT = false: B(k,j) at B[k + ldb*j];  BT = true: B(k,j) at B[j + ldb*k]
+int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a);
+
+// S[p] = K(x_p, x_p) + jitter I on the leading n x n block, identity on the pad block;
+// strict upper triangle zero unless `full`.
+int launch_k_build(hipStream_t st, const double *x, int64_t x_stride, int n, int n_pad,
+                   int batch, double ls, double sf, double jitter, double *S, bool full);
+// In-place lower Cholesky of `batch` padded matrices; inv_diag receives the inverses of
+// the TILE x TILE diagonal blocks ([TILE,TILE,n_pad/TILE,batch]); *d_info (device int) is
+// set non-zero when a pivot is not positive.
+int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv_diag, int *d_info);
+// B <- S^-1 B (two blocked triangular solves) for `batch` systems sharing the layout.
+int launch_potrs(hipStream_t st, const double *L, const double *inv_diag, int n_pad, int batch,
+                 double *B, int64_t ldb, int64_t strideB, int nrhs_pad);
+// Kst[r + n_pad*g] = sf^2 exp(-(xs_g - x_r)^2 / (2 ls^2)), zero outside r<n, g<G.
+int launch_kstar_t(hipStream_t st, const double *x, int64_t x_stride, int n, int n_pad, int batch,
+                   double ls, double sf, int G, int G_pad, double lo, double step, double *Kst);
+
+}  // namespace gpirt

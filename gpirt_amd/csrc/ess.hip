@@ -1,0 +1,330 @@
+// Per-unit kernels of the sweep: the ordinal-probit log-likelihood reductions and the
+// elliptical-slice updates of each item's latent response function f and of its
+// (beta, threshold) parameters.  A "unit" is one (item, period) pair (one item when the
+// response function is shared by all periods); one 64-lane wave owns one unit for the whole
+// shrinking-bracket loop, so units never synchronise with each other.
+//
+//   log-likelihood    utils/log_like_fn.m:3-4, link utils/sigmoid_fn.m:4,
+//                     ordinal form gpirt-sythetic.R:159-167
+//   slice update      utils/elliptical_slice.m:47-102, utils/sample_fs.m:1-6
+#include "kernels.h"
+
+namespace gpirt {
+
+constexpr int WPB = 4;  // waves (units) per workgroup
+
+__device__ inline double bcast0(double v) { return __shfl(v, 0, 64); }
+
+// ---------------------------------------------------------------------------------------
+// plain reductions (parity entry point gpirt_ordinal_loglik, end-of-sweep log-likelihood)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * WPB) void loglik_unit_kernel(
+    const double *__restrict__ g, int64_t ldg, const int8_t *__restrict__ y, int64_t ldy,
+    const double *__restrict__ bthr, int n, int U, int C, double *__restrict__ ll_unit) {
+  __shared__ double sb[WPB][MAXC + 2];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int u = blockIdx.x * WPB + w;
+  if (u >= U) return;
+  if (lane <= C) sb[w][lane] = lane == 0 ? -INFINITY : (lane == C ? INFINITY : bthr[lane + (int64_t)(C + 1) * u]);
+  double acc = 0.0;
+  for (int r = lane; r < n; r += 64) {
+    int yy = y[r + ldy * u];
+    if (yy > 0) {
+      double gg = g[r + ldg * u];
+      acc += ordinal_cell_z(sb[w][yy - 1] - gg, sb[w][yy] - gg);
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) ll_unit[u] = acc;
+}
+
+// per-row sums: thread per row, loop over units (rows contiguous across lanes)
+__global__ void loglik_row_kernel(const double *__restrict__ g, int64_t ldg,
+                                  const int8_t *__restrict__ y, int64_t ldy,
+                                  const double *__restrict__ bthr, int n, int U, int C,
+                                  double *__restrict__ ll_row) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  double acc = 0.0;
+  for (int u = 0; u < U; ++u) {
+    int yy = y[r + ldy * u];
+    if (yy > 0) {
+      const double *b = bthr + (int64_t)(C + 1) * u;
+      double lo = yy == 1 ? -INFINITY : b[yy - 1], hi = yy == C ? INFINITY : b[yy];
+      double gg = g[r + ldg * u];
+      acc += ordinal_cell_z(lo - gg, hi - gg);
+    }
+  }
+  ll_row[r] = acc;
+}
+
+int launch_loglik(hipStream_t st, const double *g, int64_t ldg, const int8_t *y, int64_t ldy,
+                  const double *bthr, int n, int U, int C, double *ll_unit, double *ll_row) {
+  if (ll_unit) {
+    hipLaunchKernelGGL(loglik_unit_kernel, dim3((U + WPB - 1) / WPB), dim3(64 * WPB), 0, st, g, ldg,
+                       y, ldy, bthr, n, U, C, ll_unit);
+    GP_HIP(hipGetLastError());
+  }
+  if (ll_row) {
+    hipLaunchKernelGGL(loglik_row_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, ldg, y, ldy,
+                       bthr, n, U, C, ll_row);
+    GP_HIP(hipGetLastError());
+  }
+  return GPIRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// standard normals for every (row, unit): Z[r + ld*u], keyed by the GLOBAL unit id so that
+// the stream does not depend on how items are sharded; zero in the pad.
+// ---------------------------------------------------------------------------------------
+__global__ void fill_normal_kernel(double *__restrict__ Z, int64_t ld, int Np, int Np_pad,
+                                   int U_pad, int mloc, int ML, int m, int j0, uint64_t seed,
+                                   uint32_t sweep) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;  // pair index along rows
+  int u = blockIdx.y;
+  if (2 * q >= Np_pad) return;
+  double z0 = 0.0, z1 = 0.0;
+  if (u % ML < mloc && 2 * q < Np) {
+    uint32_t ug = (uint32_t)((j0 + u % ML) + m * (u / ML));
+    rng_normal_pair(seed, TAG_F_Z, sweep, ug, (uint32_t)q, z0, z1);
+    if (2 * q + 1 >= Np) z1 = 0.0;
+  }
+  *reinterpret_cast<double2 *>(Z + 2 * q + ld * (int64_t)u) = make_double2(z0, z1);
+}
+
+int launch_fill_normal(hipStream_t st, double *Z, int64_t ld, int Np, int Np_pad, int U_pad,
+                       int mloc, int ML, int m, int j0, uint64_t seed, uint32_t sweep) {
+  dim3 block(256), grid((Np_pad / 2 + 255) / 256, U_pad);
+  hipLaunchKernelGGL(fill_normal_kernel, grid, block, 0, st, Z, ld, Np, Np_pad, U_pad, mloc, ML, m,
+                     j0, seed, sweep);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// `count` draws of stream (seed, tag, sweep, unit): the parity entry points gpirt_rng_*
+__global__ void rng_fill_kernel(uint64_t seed, uint32_t tag, uint32_t sweep, uint32_t unit,
+                                int64_t count, int normal, double *__restrict__ out) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (2 * q >= count) return;
+  double a, b;
+  if (normal) rng_normal_pair(seed, tag, sweep, unit, (uint32_t)q, a, b);
+  else rng_uniform_pair(seed, tag, sweep, unit, (uint32_t)q, a, b);
+  out[2 * q] = a;
+  if (2 * q + 1 < count) out[2 * q + 1] = b;
+}
+
+int launch_rng_fill(hipStream_t st, uint64_t seed, uint32_t tag, uint32_t sweep, uint32_t unit,
+                    int64_t count, int normal, double *out) {
+  int64_t pairs = (count + 1) / 2;
+  if (pairs == 0) return GPIRT_OK;
+  hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, seed,
+                     tag, sweep, unit, count, normal, out);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// slice update of f, one wave per unit (a4 + a5)
+// ---------------------------------------------------------------------------------------
+__device__ inline double ll_f_pass(const double *__restrict__ f, const double *__restrict__ nu,
+                                   const double *__restrict__ mu, const double *__restrict__ x,
+                                   double b0, double b1, double b2, const int8_t *__restrict__ y,
+                                   const double *sb, int n, int lane, double c, double s) {
+  double acc = 0.0;
+  for (int r = lane; r < n; r += 64) {
+    int yy = y[r];
+    if (yy > 0) {
+      double m_r;
+      if (mu) m_r = mu[r];
+      else { double xr = x[r]; m_r = b0 + b1 * xr + b2 * xr * xr; }
+      double pr = f[r] * c + nu[r] * s;
+      double gg = m_r + pr;
+      acc += ordinal_cell_z(sb[yy - 1] - gg, sb[yy] - gg);
+    }
+  }
+  return bcast0(wave_sum(acc));
+}
+
+__global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
+  __shared__ double sbb[WPB][MAXC + 2];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int u = blockIdx.x * WPB + w;
+  if (u >= a.U_pad || u % a.ML >= a.mloc) return;
+  double *sb = sbb[w];
+  const int C = a.C, n = a.Np;
+  if (lane <= C)
+    sb[lane] = lane == 0 ? -INFINITY : (lane == C ? INFINITY : a.bthr[lane + (int64_t)(C + 1) * u]);
+  double *f = a.f + a.ld * u;
+  const double *nu = a.nu + a.ld * u;
+  const double *mu = a.mu ? a.mu + a.ld_mu * u : nullptr;
+  const int8_t *y = a.y + a.ldy * u;
+  const double *x = a.x ? a.x + a.x_stride * (u / a.ML) : nullptr;
+  double b0 = 0, b1 = 0, b2 = 0;
+  if (a.beta) { b0 = a.beta[3 * u]; b1 = a.beta[3 * u + 1]; b2 = a.beta[3 * u + 2]; }
+  const uint32_t ug = (uint32_t)((a.j0 + u % a.ML) + a.m * (u / a.ML));
+  const double *un = a.unif ? a.unif + (int64_t)(a.R + 2) * u : nullptr;
+  auto draw = [&](int d) -> double {
+    return un ? un[d] : rng_uniform_at(a.seed, TAG_F_U, a.sweep, ug, (uint32_t)d);
+  };
+
+  const double cur = ll_f_pass(f, nu, mu, x, b0, b1, b2, y, sb, n, lane, 1.0, 0.0);
+  const double hh = log(draw(0)) + cur;              // elliptical_slice.m:66
+  double phi = draw(1) * kTwoPi;                     // :72
+  double pmin = phi - kTwoPi, pmax = phi;            // :73-74
+  int r = 0;
+  bool ok = false;
+  double l = cur, c = 1.0, s = 0.0;
+  while (r < a.R) {
+    sincos(phi, &s, &c);
+    l = ll_f_pass(f, nu, mu, x, b0, b1, b2, y, sb, n, lane, c, s);  // :85-86
+    ++r;
+    if (l > hh) { ok = true; break; }                // :87
+    if (phi > 0.0) pmax = phi;                       // :92-96
+    else if (phi < 0.0) pmin = phi;
+    else break;
+    phi = draw(1 + r) * (pmax - pmin) + pmin;        // :100
+  }
+  if (ok)
+    for (int i = lane; i < n; i += 64) f[i] = f[i] * c + nu[i] * s;
+  if (lane == 0) {
+    if (a.rounds) a.rounds[u] = ok ? r : -r;
+    if (a.ll) a.ll[u] = ok ? l : cur;
+    if (a.counters) {
+      atomicAdd(&a.counters[0], (unsigned long long)(1 + r));
+      if (!ok) atomicAdd(&a.counters[1], 1ull);
+    }
+  }
+}
+
+int launch_ess_f(hipStream_t st, const EssFArgs &a) {
+  hipLaunchKernelGGL(ess_f_kernel, dim3((a.U_pad + WPB - 1) / WPB), dim3(64 * WPB), 0, st, a);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// joint slice update of (beta, thresholds) of each unit (a8 + the IRF mean part).  The
+// vector is e[3] (whitened coefficients) and delta[C-1] (b_1 = delta_1,
+// b_c = b_{c-1} + exp(delta_c)), prior N(0,I); a switched-off coefficient and fixed
+// thresholds do not move.
+// ---------------------------------------------------------------------------------------
+constexpr int MAXD = MAXC + 2;
+
+__device__ inline void params_from_white(const double *v, const double *pm, const double *ps, int C,
+                                         double &b0, double &b1, double &b2, double *sb) {
+  b0 = pm[0] + ps[0] * v[0];
+  b1 = pm[1] + ps[1] * v[1];
+  b2 = pm[2] + ps[2] * v[2];
+  double acc = v[3];
+  sb[0] = -INFINITY;
+  sb[1] = acc;
+#pragma unroll
+  for (int c = 2; c < MAXC; ++c)
+    if (c < C) { acc += exp(v[c + 2]); sb[c] = acc; }
+  sb[C] = INFINITY;
+}
+
+__device__ inline double ll_param_pass(const double *__restrict__ f, const double *__restrict__ x,
+                                       double b0, double b1, double b2,
+                                       const int8_t *__restrict__ y, const double *sb, int n,
+                                       int lane) {
+  double acc = 0.0;
+  for (int r = lane; r < n; r += 64) {
+    int yy = y[r];
+    if (yy > 0) {
+      double xr = x[r];
+      double gg = b0 + b1 * xr + b2 * xr * xr + f[r];
+      acc += ordinal_cell_z(sb[yy - 1] - gg, sb[yy] - gg);
+    }
+  }
+  return bcast0(wave_sum(acc));
+}
+
+__global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
+  __shared__ double sbb[WPB][MAXC + 2];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int u = blockIdx.x * WPB + w;
+  if (u >= a.U_pad || u % a.ML >= a.mloc) return;
+  double *sb = sbb[w];
+  const int C = a.C, n = a.Np, D = C + 2, jl = u % a.ML;
+  const double *f = a.f + a.ld * u;
+  const int8_t *y = a.y + a.ldy * u;
+  const double *x = a.x + a.x_stride * (u / a.ML);
+  const uint32_t ug = (uint32_t)((a.j0 + jl) + a.m * (u / a.ML));
+  double pm[3], ps[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { pm[k] = a.bpm[k + 3 * jl]; ps[k] = a.bps[k + 3 * jl]; }
+
+  double v[MAXD], nv[MAXD], pv[MAXD];
+  bool anyfree = false;
+#pragma unroll
+  for (int k = 0; k < MAXD; ++k) {
+    v[k] = 0.0; nv[k] = 0.0; pv[k] = 0.0;
+    if (k < D) {
+      bool is_free = k < 3 ? (ps[k] > 0.0) : !a.fixed_thr;
+      v[k] = k < 3 ? (is_free ? a.ebeta[k + 3 * u] : 0.0) : a.delta[(k - 3) + (int64_t)(C - 1) * u];
+      nv[k] = is_free ? rng_normal_at(a.seed, TAG_P_Z, a.sweep, ug, (uint32_t)k) : 0.0;
+      anyfree |= is_free;
+    }
+  }
+  double b0, b1, b2;
+  params_from_white(v, pm, ps, C, b0, b1, b2, sb);
+  const double cur = ll_param_pass(f, x, b0, b1, b2, y, sb, n, lane);
+  int r = 0;
+  bool ok = false;
+  double l = cur;
+  if (anyfree) {
+    const double hh = log(rng_uniform_at(a.seed, TAG_P_U, a.sweep, ug, 0)) + cur;
+    double phi = rng_uniform_at(a.seed, TAG_P_U, a.sweep, ug, 1) * kTwoPi;
+    double pmin = phi - kTwoPi, pmax = phi;
+    while (r < a.R) {
+      double s, c;
+      sincos(phi, &s, &c);
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) {
+        bool rot = k < 3 ? true : !a.fixed_thr;
+        pv[k] = rot ? v[k] * c + nv[k] * s : v[k];
+      }
+      params_from_white(pv, pm, ps, C, b0, b1, b2, sb);
+      l = ll_param_pass(f, x, b0, b1, b2, y, sb, n, lane);
+      ++r;
+      if (l > hh) { ok = true; break; }
+      if (phi > 0.0) pmax = phi;
+      else if (phi < 0.0) pmin = phi;
+      else break;
+      phi = rng_uniform_at(a.seed, TAG_P_U, a.sweep, ug, (uint32_t)(1 + r)) * (pmax - pmin) + pmin;
+    }
+  }
+  if (!ok) {  // keep the current parameters
+    params_from_white(v, pm, ps, C, b0, b1, b2, sb);
+    l = cur;
+  }
+  const double *fin = ok ? pv : v;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      if (k < 3) a.ebeta[k + 3 * u] = fin[k];
+      else if (k < D) a.delta[(k - 3) + (int64_t)(C - 1) * u] = fin[k];
+    }
+    a.beta[3 * u] = b0; a.beta[3 * u + 1] = b1; a.beta[3 * u + 2] = b2;
+    a.betaS[u] = b0; a.betaS[u + a.U_pad] = b1; a.betaS[u + 2 * (int64_t)a.U_pad] = b2;
+    if (a.ll) a.ll[u] = l;
+    if (a.counters && anyfree) {
+      atomicAdd(&a.counters[0], (unsigned long long)(1 + r));
+      if (!ok) atomicAdd(&a.counters[1], 1ull);
+    }
+  }
+  if (lane <= C) {
+    double bv = sb[lane];
+    a.bthr[lane + (int64_t)(C + 1) * u] = bv;
+    a.bthrS[u + (int64_t)a.U_pad * lane] = bv;
+  }
+}
+
+int launch_ess_param(hipStream_t st, const EssParamArgs &a) {
+  hipLaunchKernelGGL(ess_param_kernel, dim3((a.U_pad + WPB - 1) / WPB), dim3(64 * WPB), 0, st, a);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+}  // namespace gpirt

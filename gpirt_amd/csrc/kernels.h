@@ -1,0 +1,83 @@
+// Argument blocks and launch prototypes of the per-unit and per-respondent kernels.
+#pragma once
+#include "common.h"
+
+namespace gpirt {
+
+constexpr int MAXC = 16;   // response categories supported on the device
+constexpr int MAXH = 64;   // periods supported by the respondent step
+
+// ---- ess.hip --------------------------------------------------------------------------
+int launch_loglik(hipStream_t st, const double *g, int64_t ldg, const int8_t *y, int64_t ldy,
+                  const double *bthr, int n, int U, int C, double *ll_unit, double *ll_row);
+
+int launch_fill_normal(hipStream_t st, double *Z, int64_t ld, int Np, int Np_pad, int U_pad,
+                       int mloc, int ML, int m, int j0, uint64_t seed, uint32_t sweep);
+
+int launch_rng_fill(hipStream_t st, uint64_t seed, uint32_t tag, uint32_t sweep, uint32_t unit,
+                    int64_t count, int normal, double *out);
+
+struct EssFArgs {
+  double *f; const double *nu; int64_t ld;   // [ld, U] latent state and ellipse draw
+  const double *mu; int64_t ld_mu;           // explicit mean (test entry) or nullptr
+  const int8_t *y; int64_t ldy;              // [ldy, U], 0 = missing
+  const double *x; int64_t x_stride;         // inputs of group p at x + x_stride*p (or nullptr)
+  const double *beta;                        // [3,U] (or nullptr with mu)
+  const double *bthr;                        // [C+1,U], ends ignored
+  const double *unif;                        // injected uniforms [R+2,U] or nullptr (Philox)
+  int Np, U_pad, C, mloc, ML, m, j0, R;   // unit u = jl + ML*p is live when jl < mloc
+  uint64_t seed; uint32_t sweep;
+  int32_t *rounds; double *ll;               // per-unit outputs (optional)
+  unsigned long long *counters;              // [0] likelihood evaluations, [1] capped updates
+};
+int launch_ess_f(hipStream_t st, const EssFArgs &a);
+
+struct EssParamArgs {
+  const double *f; int64_t ld;
+  const int8_t *y; int64_t ldy;
+  const double *x; int64_t x_stride;
+  double *ebeta;        // [3,U]   whitened coefficients (state)
+  double *delta;        // [C-1,U] unconstrained thresholds (state)
+  double *beta;         // [3,U]   out
+  double *bthr;         // [C+1,U] out (+-inf ends)
+  double *betaS;        // [U_pad,3]   out, unit-contiguous copy for the respondent step
+  double *bthrS;        // [U_pad,C+1] out, unit-contiguous copy
+  const double *bpm, *bps;  // [3,mloc] prior mean / sd
+  int fixed_thr;
+  int Np, U_pad, C, mloc, ML, m, j0, R;
+  uint64_t seed; uint32_t sweep;
+  double *ll;
+  unsigned long long *counters;
+};
+int launch_ess_param(hipStream_t st, const EssParamArgs &a);
+
+// ---- theta.hip -------------------------------------------------------------------------
+struct ThetaArgs {
+  double *theta;            // [n,H] state
+  double *xc, *nu, *prop;   // [n,H] centred state, ellipse draw, centred proposal
+  double *hh, *phi, *pmin, *pmax;  // [n]
+  int32_t *done;            // [n]
+  double *buf;              // [n] log-likelihood (partial, then all-reduced)
+  const double *Lt;         // [H,H] lower factor of the temporal kernel
+  const double *tpm, *tps;  // [2,n]
+  const double *Gt;         // [U_pad, G_pad] f* with the unit index contiguous
+  const double *betaS, *bthrS;
+  const int8_t *yT;         // [ML*H, n] responses, respondent-major
+  int n, H, C, mloc, ML, U_pad, G, constant_irf, R;
+  double grid_lo, grid_step;
+  uint64_t seed; uint32_t sweep;
+  int32_t *remaining;       // device counter
+  unsigned long long *counters;  // [1] capped
+};
+int launch_theta_prepare(hipStream_t st, const ThetaArgs &a);
+int launch_theta_eval(hipStream_t st, const ThetaArgs &a, int initial);
+int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int round);
+// f[r + ld*u] = Gt[u + U_pad * idx(x_p[r])]   (main.m:69-73)
+int launch_snap(hipStream_t st, const double *Gt, int U_pad, const double *x, int64_t x_stride,
+                int Np, int P, int mloc, int ML, int G, double lo, double step, double *f,
+                int64_t ld);
+// out[g + G*(jl + mloc*p)] = Gt[(jl + ML*p) + U_pad*g]
+int launch_export_fstar(hipStream_t st, const double *Gt, int U_pad, int G, int P, int mloc, int ML,
+                        double *out);
+
+}  // namespace gpirt

@@ -1,0 +1,867 @@
+// Host side of the C ABI declared in include/gpirt.h: the resident sampler (one Gibbs
+// sweep = main.m:46-87), gpirt_run (one chain of gpirtMCMC, gpirt-sythetic.R:88-94) and the
+// parity entry points that expose the same device kernels with injected inputs.
+#include "kernels.h"
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace gpirt {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+// ---- small RAII helpers for the entry points ---------------------------------------------
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes, bool zero = true) {
+    GP_HIP(hipMalloc(&p, bytes ? bytes : 8));
+    if (zero) GP_HIP(hipMemset(p, 0, bytes ? bytes : 8));
+    return GPIRT_OK;
+  }
+  template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+static int have_device() {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess || c < 1) {
+    set_error("no HIP device visible: the gfx950 kernels cannot run (there is no CPU fallback)");
+    return GPIRT_ERR_NO_DEVICE;
+  }
+  return GPIRT_OK;
+}
+
+// host column-major [rows, cols] -> device padded [ld, cols_pad] (zero pad)
+static int upload_padded(const double *h, int rows, int cols, double *d, int64_t ld, hipStream_t st) {
+  GP_HIP(hipMemcpy2DAsync(d, sizeof(double) * ld, h, sizeof(double) * rows, sizeof(double) * rows,
+                          cols, hipMemcpyHostToDevice, st));
+  return GPIRT_OK;
+}
+static int download_padded(double *h, int rows, int cols, const double *d, int64_t ld, hipStream_t st) {
+  GP_HIP(hipMemcpy2DAsync(h, sizeof(double) * rows, d, sizeof(double) * ld, sizeof(double) * rows,
+                          cols, hipMemcpyDeviceToHost, st));
+  return GPIRT_OK;
+}
+
+static double temporal_k(const gpirt_config &c, double d) {
+  if (c.theta_os == 0.0) return (c.theta_ls < 0.0) ? 1.0 : (d == 0.0 ? 1.0 : 0.0);
+  double os2 = c.theta_os * c.theta_os;
+  if (c.theta_ls <= 0.0) return os2;
+  double a = fabs(d) / c.theta_ls;
+  if (c.kernel == GPIRT_KERNEL_MATERN52) {
+    double q = 2.2360679774997896964 * a;
+    return os2 * (1.0 + q + q * q / 3.0) * exp(-q);
+  }
+  return os2 * exp(-0.5 * a * a);
+}
+
+static int host_chol_lower(std::vector<double> &A, int n) {
+  for (int j = 0; j < n; ++j) {
+    double d = A[j + (size_t)n * j];
+    for (int k = 0; k < j; ++k) d -= A[j + (size_t)n * k] * A[j + (size_t)n * k];
+    if (!(d > 0.0)) return j + 1;
+    d = sqrt(d);
+    A[j + (size_t)n * j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = A[i + (size_t)n * j];
+      for (int k = 0; k < j; ++k) s -= A[i + (size_t)n * k] * A[j + (size_t)n * k];
+      A[i + (size_t)n * j] = s / d;
+    }
+    for (int i = 0; i < j; ++i) A[i + (size_t)n * j] = 0.0;
+  }
+  return 0;
+}
+
+}  // namespace gpirt
+
+using namespace gpirt;
+
+enum { PH_KBUILD = 0, PH_POTRF, PH_NU, PH_ESSF, PH_PARAM, PH_FSTAR, PH_THETA, PH_SNAP, PH_COUNT };
+
+struct gpirt_sampler {
+  gpirt_config cfg;
+  int n, m, H, C, P, Np, Np_pad, mloc, ML, U_pad, G, G_pad, j0, nb, fixed_thr, device;
+  uint64_t seed;
+  uint32_t sweep;
+  double jitter_now;
+  hipStream_t st;
+  int8_t *d_y, *d_yT;
+  double *d_theta, *d_f, *d_Z, *d_nu, *d_S, *d_inv, *d_W, *d_Gt;
+  double *d_ebeta, *d_delta, *d_beta, *d_bthr, *d_betaS, *d_bthrS, *d_bpm, *d_bps;
+  double *d_xc, *d_tnu, *d_prop, *d_hh, *d_phi, *d_pmin, *d_pmax, *d_buf, *d_Lt, *d_tpm, *d_tps;
+  double *d_llu;
+  int32_t *d_done, *d_info, *d_remaining;
+  unsigned long long *d_counters;  // [3][2]: f, param, theta x (evaluations, capped)
+  int64_t theta_rounds;
+  int jitter_retries;
+  double phase_ms[PH_COUNT];
+  int64_t phase_cnt[PH_COUNT];
+  std::vector<hipEvent_t> ev;
+  size_t ev_used;
+  std::vector<int> ev_phase;
+};
+
+static void sampler_free(gpirt_sampler *s) {
+  if (!s) return;
+  void *ptrs[] = {s->d_y, s->d_yT, s->d_theta, s->d_f, s->d_Z, s->d_nu, s->d_S, s->d_inv, s->d_W,
+                  s->d_Gt, s->d_ebeta, s->d_delta, s->d_beta, s->d_bthr, s->d_betaS, s->d_bthrS,
+                  s->d_bpm, s->d_bps, s->d_xc, s->d_tnu, s->d_prop, s->d_hh, s->d_phi, s->d_pmin,
+                  s->d_pmax, s->d_buf, s->d_Lt, s->d_tpm, s->d_tps, s->d_llu, s->d_done, s->d_info,
+                  s->d_remaining, s->d_counters};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+  if (s->st) (void)hipStreamDestroy(s->st);
+  delete s;
+}
+
+template <typename T>
+static int dalloc(T *&p, size_t count) {
+  GP_HIP(hipMalloc((void **)&p, (count ? count : 1) * sizeof(T)));
+  GP_HIP(hipMemset(p, 0, (count ? count : 1) * sizeof(T)));
+  return GPIRT_OK;
+}
+
+static void params_host(const gpirt_sampler *s, int jl, const double *e, const double *dl,
+                        double *beta, double *b, const double *bpm, const double *bps) {
+  for (int k = 0; k < 3; ++k) beta[k] = bpm[k + 3 * jl] + bps[k + 3 * jl] * e[k];
+  int C = s->C;
+  b[0] = -INFINITY; b[C] = INFINITY;
+  b[1] = dl[0];
+  for (int c = 2; c < C; ++c) b[c] = b[c - 1] + exp(dl[c - 1]);
+}
+
+static int check_cfg(const gpirt_config *cfg) {
+  if (!cfg) { set_error("cfg is NULL"); return GPIRT_ERR_BAD_ARG; }
+  if (cfg->struct_size != (int32_t)sizeof(gpirt_config)) {
+    set_error("gpirt_config.struct_size %d != %zu (header mismatch)", cfg->struct_size,
+              sizeof(gpirt_config));
+    return GPIRT_ERR_BAD_ARG;
+  }
+  if (cfg->n < 1 || cfg->m < 1 || cfg->H < 1 || cfg->H > MAXH || cfg->C < 2 || cfg->C > MAXC) {
+    set_error("bad shape n=%d m=%d H=%d (max %d) C=%d (2..%d)", cfg->n, cfg->m, cfg->H, MAXH, cfg->C,
+              MAXC);
+    return GPIRT_ERR_BAD_ARG;
+  }
+  if (cfg->n_grid < 2 || !(cfg->grid_step > 0) || !(cfg->irf_ls > 0) || !(cfg->jitter >= 0)) {
+    set_error("bad grid / kernel hyper-parameters");
+    return GPIRT_ERR_BAD_ARG;
+  }
+  if (cfg->theta_mode != GPIRT_THETA_ESS) {
+    set_error("theta_mode %d is not available on the device yet (only GPIRT_THETA_ESS)", cfg->theta_mode);
+    return GPIRT_ERR_BAD_ARG;
+  }
+  if (cfg->world > 1 && !cfg->allreduce) {
+    set_error("world=%d needs an allreduce hook", cfg->world);
+    return GPIRT_ERR_BAD_ARG;
+  }
+  if (cfg->item_end > cfg->item_begin && (cfg->item_begin < 0 || cfg->item_end > cfg->m)) {
+    set_error("item range [%d,%d) outside [0,%d)", cfg->item_begin, cfg->item_end, cfg->m);
+    return GPIRT_ERR_BAD_ARG;
+  }
+  return GPIRT_OK;
+}
+
+extern "C" {
+
+const char *gpirt_version(void) { return "gpirt-hip 0.1 (gfx950)"; }
+const char *gpirt_last_error(void) { return g_err; }
+
+int gpirt_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+int gpirt_set_device(int device) {
+  GP_TRY(have_device());
+  GP_HIP(hipSetDevice(device));
+  return GPIRT_OK;
+}
+
+void gpirt_config_defaults(gpirt_config *c) {
+  memset(c, 0, sizeof *c);
+  c->struct_size = (int32_t)sizeof *c;
+  c->H = 1; c->C = 2;
+  c->sample_iterations = 500; c->burn_iterations = 500; c->thin = 1;
+  c->seed = 1;
+  c->theta_os = 1.0; c->theta_ls = 1.0;
+  c->kernel = GPIRT_KERNEL_RBF;
+  c->jitter = 1e-6; c->irf_ls = 1.0; c->irf_sf = 1.0;
+  c->n_grid = 1001; c->grid_lo = -5.0; c->grid_step = 0.01;
+  c->theta_mode = GPIRT_THETA_ESS;
+  c->max_ess_rounds = 200;
+  c->world = 1;
+}
+
+int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double *theta_init,
+                         const double *bpm_in, const double *bps_in, const double *tpm_in,
+                         const double *tps_in, const double *thresholds, gpirt_sampler **out) {
+  GP_TRY(check_cfg(cfg));
+  if (!y || !out) { set_error("y/out is NULL"); return GPIRT_ERR_BAD_ARG; }
+  GP_TRY(have_device());
+  gpirt_sampler *s = new gpirt_sampler();  // value-initialised: every scalar and pointer is 0
+  s->cfg = *cfg;
+  if (s->cfg.max_ess_rounds <= 0) s->cfg.max_ess_rounds = 200;
+  s->n = cfg->n; s->m = cfg->m; s->H = cfg->H; s->C = cfg->C; s->G = cfg->n_grid;
+  s->P = cfg->constant_irf ? 1 : cfg->H;
+  s->Np = cfg->constant_irf ? cfg->n * cfg->H : cfg->n;
+  s->j0 = cfg->item_end > cfg->item_begin ? cfg->item_begin : 0;
+  int j1 = cfg->item_end > cfg->item_begin ? cfg->item_end : cfg->m;
+  s->mloc = j1 - s->j0;
+  s->ML = (int)pad_up(s->mloc);
+  s->U_pad = s->ML * s->P;
+  s->Np_pad = (int)pad_up(s->Np);
+  s->G_pad = (int)pad_up(s->G);
+  s->nb = s->Np_pad / TILE;
+  s->seed = cfg->seed + 0x9E3779B97F4A7C15ull * (uint64_t)cfg->chain;
+  s->jitter_now = cfg->jitter;
+  s->fixed_thr = thresholds != nullptr;
+  const int n = s->n, m = s->m, H = s->H, C = s->C, P = s->P, Np = s->Np, Np_pad = s->Np_pad,
+            mloc = s->mloc, ML = s->ML, U_pad = s->U_pad, G_pad = s->G_pad;
+  int rc = GPIRT_OK;
+  auto fail = [&](int code) { sampler_free(s); return code; };
+  if (hipGetDevice(&s->device) != hipSuccess) return fail(GPIRT_ERR_HIP);
+  if (hipStreamCreate(&s->st) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(GPIRT_ERR_HIP); }
+
+#define A_(ptr, count) if ((rc = dalloc(ptr, (size_t)(count)))) return fail(rc)
+  A_(s->d_y, (size_t)Np_pad * U_pad);
+  A_(s->d_yT, (size_t)ML * H * n);
+  A_(s->d_theta, (size_t)n * H);
+  A_(s->d_f, (size_t)Np_pad * U_pad);
+  A_(s->d_Z, (size_t)Np_pad * U_pad);
+  A_(s->d_nu, (size_t)Np_pad * U_pad);
+  A_(s->d_S, (size_t)Np_pad * Np_pad * P);
+  A_(s->d_inv, (size_t)TILE * TILE * s->nb * P);
+  A_(s->d_W, (size_t)Np_pad * G_pad * P);
+  A_(s->d_Gt, (size_t)U_pad * G_pad);
+  A_(s->d_ebeta, 3 * (size_t)U_pad);
+  A_(s->d_delta, (size_t)(C - 1) * U_pad);
+  A_(s->d_beta, 3 * (size_t)U_pad);
+  A_(s->d_bthr, (size_t)(C + 1) * U_pad);
+  A_(s->d_betaS, 3 * (size_t)U_pad);
+  A_(s->d_bthrS, (size_t)(C + 1) * U_pad);
+  A_(s->d_bpm, 3 * (size_t)mloc);
+  A_(s->d_bps, 3 * (size_t)mloc);
+  A_(s->d_xc, (size_t)n * H);
+  A_(s->d_tnu, (size_t)n * H);
+  A_(s->d_prop, (size_t)n * H);
+  A_(s->d_hh, n); A_(s->d_phi, n); A_(s->d_pmin, n); A_(s->d_pmax, n); A_(s->d_buf, n);
+  A_(s->d_Lt, (size_t)H * H);
+  A_(s->d_tpm, 2 * (size_t)n); A_(s->d_tps, 2 * (size_t)n);
+  A_(s->d_llu, U_pad);
+  A_(s->d_done, n); A_(s->d_info, 1); A_(s->d_remaining, 1);
+  A_(s->d_counters, 6);
+#undef A_
+
+  // ---- host staging -------------------------------------------------------------------
+  std::vector<int8_t> hy((size_t)Np_pad * U_pad, 0), hyT((size_t)ML * H * n, 0);
+  for (int h = 0; h < H; ++h)
+    for (int jl = 0; jl < mloc; ++jl)
+      for (int i = 0; i < n; ++i) {
+        int8_t v = y[i + (size_t)n * ((s->j0 + jl) + (size_t)m * h)];
+        if (v < 0 || v > C) v = 0;
+        size_t u = cfg->constant_irf ? (size_t)jl : (size_t)jl + (size_t)ML * h;
+        size_t r = cfg->constant_irf ? (size_t)i + (size_t)n * h : (size_t)i;
+        hy[r + (size_t)Np_pad * u] = v;
+        hyT[(size_t)ML * H * i + (size_t)ML * h + jl] = v;
+      }
+  std::vector<double> hth((size_t)n * H);
+  for (int h = 0; h < H; ++h)
+    for (int i = 0; i < n; ++i)
+      hth[i + (size_t)n * h] = theta_init ? theta_init[i + (size_t)n * h]
+                                          : rng_normal_at(s->seed, TAG_INIT, 0, (uint32_t)i, 0);
+  std::vector<double> hbpm(3 * (size_t)mloc), hbps(3 * (size_t)mloc);
+  for (int jl = 0; jl < mloc; ++jl)
+    for (int k = 0; k < 3; ++k) {
+      hbpm[k + 3 * jl] = bpm_in ? bpm_in[k + 3 * (size_t)(s->j0 + jl)] : 0.0;
+      hbps[k + 3 * jl] = bps_in ? bps_in[k + 3 * (size_t)(s->j0 + jl)] : 1.0;
+    }
+  std::vector<double> heb(3 * (size_t)U_pad, 0.0), hdl((size_t)(C - 1) * U_pad, 0.0),
+      hbeta(3 * (size_t)U_pad, 0.0), hb((size_t)(C + 1) * U_pad, 0.0),
+      hbetaS(3 * (size_t)U_pad, 0.0), hbS((size_t)(C + 1) * U_pad, 0.0);
+  for (int p = 0; p < P; ++p)
+    for (int jl = 0; jl < mloc; ++jl) {
+      size_t u = (size_t)jl + (size_t)ML * p;
+      double b[MAXC + 2], beta[3];
+      for (int c = 1; c < C; ++c)
+        b[c] = thresholds ? thresholds[c] : (C == 2 ? 0.0 : -1.5 + 3.0 * (double)(c - 1) / (double)(C - 2));
+      double *dl = &hdl[(size_t)(C - 1) * u];
+      dl[0] = b[1];
+      for (int c = 2; c < C; ++c) dl[c - 1] = log(b[c] - b[c - 1]);
+      params_host(s, jl, &heb[3 * u], dl, beta, b, hbpm.data(), hbps.data());
+      for (int k = 0; k < 3; ++k) { hbeta[k + 3 * u] = beta[k]; hbetaS[u + (size_t)U_pad * k] = beta[k]; }
+      for (int c = 0; c <= C; ++c) { hb[c + (size_t)(C + 1) * u] = b[c]; hbS[u + (size_t)U_pad * c] = b[c]; }
+    }
+  std::vector<double> hLt((size_t)H * H);
+  for (int a = 0; a < H; ++a)
+    for (int b2 = 0; b2 < H; ++b2)
+      hLt[a + (size_t)H * b2] = temporal_k(*cfg, (double)(a - b2)) + (a == b2 ? 1e-6 : 0.0);
+  if (host_chol_lower(hLt, H)) {
+    set_error("temporal kernel (theta_os=%g, theta_ls=%g) is not positive definite", cfg->theta_os,
+              cfg->theta_ls);
+    return fail(GPIRT_ERR_NOT_PD);
+  }
+  std::vector<double> htpm(2 * (size_t)n, 0.0), htps(2 * (size_t)n, 0.0);
+  if (tpm_in) memcpy(htpm.data(), tpm_in, sizeof(double) * 2 * n);
+  if (tps_in) memcpy(htps.data(), tps_in, sizeof(double) * 2 * n);
+
+#define UP_(dst, vec) \
+  if (hipMemcpy(dst, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice) != hipSuccess) { \
+    set_error("upload of " #vec " failed"); return fail(GPIRT_ERR_HIP); }
+  UP_(s->d_y, hy); UP_(s->d_yT, hyT); UP_(s->d_theta, hth); UP_(s->d_bpm, hbpm); UP_(s->d_bps, hbps);
+  UP_(s->d_ebeta, heb); UP_(s->d_delta, hdl); UP_(s->d_beta, hbeta); UP_(s->d_bthr, hb);
+  UP_(s->d_betaS, hbetaS); UP_(s->d_bthrS, hbS); UP_(s->d_Lt, hLt); UP_(s->d_tpm, htpm);
+  UP_(s->d_tps, htps);
+#undef UP_
+  *out = s;
+  return GPIRT_OK;
+}
+
+}  // extern "C"
+
+// ---- phases -----------------------------------------------------------------------------
+static int mark(gpirt_sampler *s, int phase) {
+  if (s->ev_used == s->ev.size()) {
+    hipEvent_t e;
+    GP_HIP(hipEventCreate(&e));
+    s->ev.push_back(e);
+    s->ev_phase.push_back(0);
+  }
+  s->ev_phase[s->ev_used] = phase;
+  GP_HIP(hipEventRecord(s->ev[s->ev_used], s->st));
+  s->ev_used++;
+  return GPIRT_OK;
+}
+
+// events are recorded as (begin of phase k); the time of phase k is the gap to the next mark
+static int collect_times(gpirt_sampler *s) {
+  for (size_t i = 0; i + 1 < s->ev_used; ++i) {
+    int ph = s->ev_phase[i];
+    if (ph < 0) continue;
+    float ms = 0;
+    GP_HIP(hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]));
+    s->phase_ms[ph] += ms;
+    s->phase_cnt[ph] += 1;
+  }
+  s->ev_used = 0;
+  return GPIRT_OK;
+}
+
+static int phase_factor(gpirt_sampler *s) {
+  for (;;) {
+    GP_TRY(mark(s, PH_KBUILD));
+    GP_TRY(launch_k_build(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
+                          s->cfg.irf_sf, s->jitter_now, s->d_S, false));
+    GP_TRY(mark(s, PH_POTRF));
+    GP_HIP(hipMemsetAsync(s->d_info, 0, sizeof(int), s->st));
+    GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info));
+    int info = 0;
+    GP_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    GP_HIP(hipStreamSynchronize(s->st));
+    if (!info) return GPIRT_OK;
+    if (s->jitter_now >= 1e-2) {
+      set_error("K(theta,theta)+%g I is not positive definite (pivot %d)", s->jitter_now, info);
+      return GPIRT_ERR_NOT_PD;
+    }
+    s->jitter_now *= 10.0;
+    s->jitter_retries++;
+  }
+}
+
+static int phase_f(gpirt_sampler *s) {
+  GP_TRY(mark(s, PH_NU));
+  GP_TRY(launch_fill_normal(s->st, s->d_Z, s->Np_pad, s->Np, s->Np_pad, s->U_pad, s->mloc, s->ML,
+                            s->m, s->j0, s->seed, s->sweep));
+  GemmArgs g{};  // nu = L z for every unit at once (sample_fs.m:2)
+  g.A = s->d_S; g.lda = s->Np_pad; g.strideA = (int64_t)s->Np_pad * s->Np_pad;
+  g.B = s->d_Z; g.ldb = s->Np_pad; g.strideB = (int64_t)s->Np_pad * s->ML;
+  g.C = s->d_nu; g.ldc = s->Np_pad; g.strideC = (int64_t)s->Np_pad * s->ML;
+  g.M = s->Np_pad; g.N = s->ML; g.K = s->Np_pad; g.batch = s->P; g.alpha = 1.0; g.beta = 0.0;
+  g.k_trim = 1;
+  GP_TRY(launch_gemm(s->st, false, false, g));
+  GP_TRY(mark(s, PH_ESSF));
+  EssFArgs a{};
+  a.f = s->d_f; a.nu = s->d_nu; a.ld = s->Np_pad; a.mu = nullptr; a.ld_mu = 0;
+  a.y = s->d_y; a.ldy = s->Np_pad; a.x = s->d_theta; a.x_stride = s->Np;
+  a.beta = s->d_beta; a.bthr = s->d_bthr; a.unif = nullptr;
+  a.Np = s->Np; a.U_pad = s->U_pad; a.C = s->C; a.mloc = s->mloc; a.ML = s->ML; a.m = s->m;
+  a.j0 = s->j0; a.R = s->cfg.max_ess_rounds; a.seed = s->seed; a.sweep = s->sweep;
+  a.rounds = nullptr; a.ll = nullptr; a.counters = s->d_counters;
+  GP_TRY(launch_ess_f(s->st, a));
+  return GPIRT_OK;
+}
+
+static int phase_param(gpirt_sampler *s) {
+  GP_TRY(mark(s, PH_PARAM));
+  EssParamArgs a{};
+  a.f = s->d_f; a.ld = s->Np_pad; a.y = s->d_y; a.ldy = s->Np_pad; a.x = s->d_theta;
+  a.x_stride = s->Np; a.ebeta = s->d_ebeta; a.delta = s->d_delta; a.beta = s->d_beta;
+  a.bthr = s->d_bthr; a.betaS = s->d_betaS; a.bthrS = s->d_bthrS; a.bpm = s->d_bpm; a.bps = s->d_bps;
+  a.fixed_thr = s->fixed_thr; a.Np = s->Np; a.U_pad = s->U_pad; a.C = s->C; a.mloc = s->mloc;
+  a.ML = s->ML; a.m = s->m; a.j0 = s->j0; a.R = s->cfg.max_ess_rounds; a.seed = s->seed;
+  a.sweep = s->sweep; a.ll = s->d_llu; a.counters = s->d_counters + 2;
+  GP_TRY(launch_ess_param(s->st, a));
+  return GPIRT_OK;
+}
+
+static int phase_fstar(gpirt_sampler *s) {
+  GP_TRY(mark(s, PH_FSTAR));
+  // W = S^-1 K(x, xs); then f*^T = F^T W   (gp posterior mean, main.m:57-58)
+  GP_TRY(launch_kstar_t(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
+                        s->cfg.irf_sf, s->G, s->G_pad, s->cfg.grid_lo, s->cfg.grid_step, s->d_W));
+  GP_TRY(launch_potrs(s->st, s->d_S, s->d_inv, s->Np_pad, s->P, s->d_W, s->Np_pad,
+                      (int64_t)s->Np_pad * s->G_pad, s->G_pad));
+  GemmArgs g{};
+  g.A = s->d_f; g.lda = s->Np_pad; g.strideA = (int64_t)s->Np_pad * s->ML;
+  g.B = s->d_W; g.ldb = s->Np_pad; g.strideB = (int64_t)s->Np_pad * s->G_pad;
+  g.C = s->d_Gt; g.ldc = s->U_pad; g.strideC = s->ML;
+  g.M = s->ML; g.N = s->G_pad; g.K = s->Np_pad; g.batch = s->P; g.alpha = 1.0; g.beta = 0.0;
+  GP_TRY(launch_gemm(s->st, true, false, g));
+  return GPIRT_OK;
+}
+
+static ThetaArgs theta_args(gpirt_sampler *s) {
+  ThetaArgs a{};
+  a.theta = s->d_theta; a.xc = s->d_xc; a.nu = s->d_tnu; a.prop = s->d_prop; a.hh = s->d_hh;
+  a.phi = s->d_phi; a.pmin = s->d_pmin; a.pmax = s->d_pmax; a.done = s->d_done; a.buf = s->d_buf;
+  a.Lt = s->d_Lt; a.tpm = s->d_tpm; a.tps = s->d_tps; a.Gt = s->d_Gt; a.betaS = s->d_betaS;
+  a.bthrS = s->d_bthrS; a.yT = s->d_yT; a.n = s->n; a.H = s->H; a.C = s->C; a.mloc = s->mloc;
+  a.ML = s->ML; a.U_pad = s->U_pad; a.G = s->G; a.constant_irf = s->cfg.constant_irf;
+  a.R = s->cfg.max_ess_rounds; a.grid_lo = s->cfg.grid_lo; a.grid_step = s->cfg.grid_step;
+  a.seed = s->seed; a.sweep = s->sweep; a.remaining = s->d_remaining;
+  a.counters = s->d_counters + 4;
+  return a;
+}
+
+// sum the per-respondent partial log-likelihoods over the ranks that share the chain
+static int exchange(gpirt_sampler *s) {
+  if (s->cfg.world <= 1) return GPIRT_OK;
+  GP_HIP(hipStreamSynchronize(s->st));
+  if (s->cfg.allreduce(s->d_buf, s->n, s->cfg.allreduce_user)) {
+    set_error("allreduce hook failed");
+    return GPIRT_ERR_COMM;
+  }
+  return GPIRT_OK;
+}
+
+static int phase_theta(gpirt_sampler *s) {
+  GP_TRY(mark(s, PH_THETA));
+  ThetaArgs a = theta_args(s);
+  GP_TRY(launch_theta_prepare(s->st, a));
+  GP_TRY(launch_theta_eval(s->st, a, 1));
+  GP_TRY(exchange(s));
+  s->theta_rounds++;
+  GP_HIP(hipMemsetAsync(s->d_remaining, 0, sizeof(int), s->st));
+  GP_TRY(launch_theta_decide(s->st, a, 0));
+  for (int r = 1; r <= a.R; ++r) {
+    GP_TRY(launch_theta_eval(s->st, a, 0));
+    GP_TRY(exchange(s));
+    s->theta_rounds++;
+    GP_HIP(hipMemsetAsync(s->d_remaining, 0, sizeof(int), s->st));
+    GP_TRY(launch_theta_decide(s->st, a, r));
+    int remaining = 0;
+    GP_HIP(hipMemcpyAsync(&remaining, s->d_remaining, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    GP_HIP(hipStreamSynchronize(s->st));
+    if (!remaining) break;
+  }
+  return GPIRT_OK;
+}
+
+static int phase_snap(gpirt_sampler *s) {
+  GP_TRY(mark(s, PH_SNAP));
+  GP_TRY(launch_snap(s->st, s->d_Gt, s->U_pad, s->d_theta, s->Np, s->Np, s->P, s->mloc, s->ML, s->G,
+                     s->cfg.grid_lo, s->cfg.grid_step, s->d_f, s->Np_pad));
+  return GPIRT_OK;
+}
+
+extern "C" {
+
+int gpirt_sampler_sweep(gpirt_sampler *s, int32_t sweeps) {
+  if (!s) { set_error("sampler is NULL"); return GPIRT_ERR_BAD_ARG; }
+  GP_HIP(hipSetDevice(s->device));
+  for (int it = 0; it < sweeps; ++it) {
+    GP_TRY(phase_factor(s));   // main.m:67 + the chol of sample_fs.m:2
+    GP_TRY(phase_f(s));        // main.m:50-52
+    GP_TRY(phase_param(s));
+    GP_TRY(phase_fstar(s));    // main.m:55-60
+    GP_TRY(phase_theta(s));    // main.m:63
+    GP_TRY(phase_snap(s));     // main.m:69-73
+    GP_TRY(mark(s, -1));
+    s->sweep++;
+    if (s->ev_used > 4096) {
+      GP_HIP(hipStreamSynchronize(s->st));
+      GP_TRY(collect_times(s));
+    }
+  }
+  GP_HIP(hipStreamSynchronize(s->st));
+  GP_TRY(collect_times(s));
+  return GPIRT_OK;
+}
+
+int gpirt_sampler_get_state(gpirt_sampler *s, double *theta, double *f, double *fstar, double *beta,
+                            double *threshold) {
+  if (!s) { set_error("sampler is NULL"); return GPIRT_ERR_BAD_ARG; }
+  GP_HIP(hipSetDevice(s->device));
+  const int n = s->n, H = s->H, C = s->C, P = s->P, mloc = s->mloc, ML = s->ML, U_pad = s->U_pad,
+            Np_pad = s->Np_pad, G = s->G;
+  GP_HIP(hipStreamSynchronize(s->st));
+  if (theta) GP_HIP(hipMemcpy(theta, s->d_theta, sizeof(double) * n * H, hipMemcpyDeviceToHost));
+  if (f) {
+    if (!s->cfg.constant_irf) {
+      for (int h = 0; h < H; ++h)
+        GP_HIP(hipMemcpy2D(f + (size_t)n * mloc * h, sizeof(double) * n,
+                           s->d_f + (size_t)Np_pad * ML * h, sizeof(double) * Np_pad,
+                           sizeof(double) * n, mloc, hipMemcpyDeviceToHost));
+    } else {
+      std::vector<double> tmp((size_t)Np_pad * mloc);
+      GP_HIP(hipMemcpy(tmp.data(), s->d_f, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+      for (int h = 0; h < H; ++h)
+        for (int jl = 0; jl < mloc; ++jl)
+          memcpy(f + (size_t)n * (jl + (size_t)mloc * h), &tmp[(size_t)n * h + (size_t)Np_pad * jl],
+                 sizeof(double) * n);
+    }
+  }
+  if (fstar) {
+    DevBuf tmp;
+    GP_TRY(tmp.alloc(sizeof(double) * (size_t)G * mloc * P, false));
+    GP_TRY(launch_export_fstar(s->st, s->d_Gt, U_pad, G, P, mloc, ML, tmp.as<double>()));
+    GP_HIP(hipStreamSynchronize(s->st));
+    GP_HIP(hipMemcpy(fstar, tmp.p, sizeof(double) * (size_t)G * mloc * P, hipMemcpyDeviceToHost));
+  }
+  if (beta) {
+    for (int p = 0; p < P; ++p)
+      GP_HIP(hipMemcpy(beta + 3 * (size_t)mloc * p, s->d_beta + 3 * (size_t)ML * p,
+                       sizeof(double) * 3 * mloc, hipMemcpyDeviceToHost));
+  }
+  if (threshold) {
+    std::vector<double> hb((size_t)(C + 1) * U_pad);
+    GP_HIP(hipMemcpy(hb.data(), s->d_bthr, sizeof(double) * hb.size(), hipMemcpyDeviceToHost));
+    for (int p = 0; p < P; ++p)
+      for (int c = 0; c <= C; ++c)
+        for (int jl = 0; jl < mloc; ++jl)
+          threshold[jl + (size_t)mloc * (c + (size_t)(C + 1) * p)] =
+              hb[c + (size_t)(C + 1) * (jl + (size_t)ML * p)];
+  }
+  return GPIRT_OK;
+}
+
+int gpirt_sampler_phase_times(gpirt_sampler *s, double *ms, int64_t *count) {
+  if (!s) { set_error("sampler is NULL"); return GPIRT_ERR_BAD_ARG; }
+  for (int k = 0; k < PH_COUNT; ++k) {
+    if (ms) ms[k] = s->phase_ms[k];
+    if (count) count[k] = s->phase_cnt[k];
+  }
+  return GPIRT_OK;
+}
+
+int gpirt_sampler_diagnostics(gpirt_sampler *s, gpirt_outputs *o) {
+  if (!s || !o) { set_error("NULL argument"); return GPIRT_ERR_BAD_ARG; }
+  GP_HIP(hipSetDevice(s->device));
+  unsigned long long c[6];
+  GP_HIP(hipStreamSynchronize(s->st));
+  GP_HIP(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
+  o->ess_f_rounds = (int64_t)c[0];
+  o->ess_param_rounds = (int64_t)c[2];
+  o->ess_theta_rounds = s->theta_rounds;
+  o->ess_capped = (int64_t)(c[1] + c[3] + c[5]);
+  o->jitter_retries = s->jitter_retries;
+  return GPIRT_OK;
+}
+
+void *gpirt_sampler_stream(gpirt_sampler *s) { return s ? (void *)s->st : nullptr; }
+
+void gpirt_sampler_destroy(gpirt_sampler *s) {
+  if (s) {
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->st);
+  }
+  sampler_free(s);
+}
+
+// end-of-sweep log-likelihood of this rank's items at the current (theta, f, beta, b)
+static int sampler_loglik(gpirt_sampler *s, double *out) {
+  // g = mu + f is evaluated inside the per-unit slice kernel with zero rounds allowed:
+  // R = 0 makes it return the log-likelihood of the current state.
+  EssFArgs a{};
+  a.f = s->d_f; a.nu = s->d_f; a.ld = s->Np_pad; a.y = s->d_y; a.ldy = s->Np_pad; a.x = s->d_theta;
+  a.x_stride = s->Np; a.beta = s->d_beta; a.bthr = s->d_bthr; a.Np = s->Np; a.U_pad = s->U_pad;
+  a.C = s->C; a.mloc = s->mloc; a.ML = s->ML; a.m = s->m; a.j0 = s->j0; a.R = 0; a.seed = s->seed;
+  a.sweep = s->sweep; a.ll = s->d_llu;
+  GP_HIP(hipMemsetAsync(s->d_llu, 0, sizeof(double) * s->U_pad, s->st));
+  GP_TRY(launch_ess_f(s->st, a));
+  std::vector<double> h(s->U_pad);
+  GP_HIP(hipMemcpyAsync(h.data(), s->d_llu, sizeof(double) * s->U_pad, hipMemcpyDeviceToHost, s->st));
+  GP_HIP(hipStreamSynchronize(s->st));
+  double acc = 0.0;
+  for (int p = 0; p < s->P; ++p)
+    for (int jl = 0; jl < s->mloc; ++jl) acc += h[jl + (size_t)s->ML * p];
+  *out = acc;
+  return GPIRT_OK;
+}
+
+int gpirt_run(const gpirt_config *cfg, const int8_t *y, const double *theta_init,
+              const double *bpm, const double *bps, const double *tpm, const double *tps,
+              const double *thresholds, gpirt_outputs *out) {
+  gpirt_sampler *s = nullptr;
+  GP_TRY(gpirt_sampler_create(cfg, y, theta_init, bpm, bps, tpm, tps, thresholds, &s));
+  const int total = cfg->burn_iterations + cfg->sample_iterations;
+  const int thin = cfg->thin > 0 ? cfg->thin : 1;
+  const int K = cfg->sample_iterations / thin;
+  int k = 0, rc = GPIRT_OK;
+  const size_t nH = (size_t)s->n * s->H, sf = (size_t)s->n * s->mloc * s->H,
+               sfs = (size_t)s->G * s->mloc * s->P, sb = 3 * (size_t)s->mloc * s->P,
+               stt = (size_t)(s->C + 1) * s->mloc * s->P;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int it = 0; it < total && rc == GPIRT_OK; ++it) {
+    rc = gpirt_sampler_sweep(s, 1);
+    if (rc) break;
+    if (out && out->loglik) rc = sampler_loglik(s, &out->loglik[it]);
+    if (rc) break;
+    int post = it - cfg->burn_iterations;
+    if (out && post >= 0 && (post + 1) % thin == 0 && k < K) {
+      rc = gpirt_sampler_get_state(
+          s, out->theta ? out->theta + nH * k : nullptr,
+          (out->f && (cfg->flags & GPIRT_RETURN_F)) ? out->f + sf * k : nullptr,
+          (out->fstar && (cfg->flags & GPIRT_RETURN_FSTAR)) ? out->fstar + sfs * k : nullptr,
+          out->beta ? out->beta + sb * k : nullptr, out->threshold ? out->threshold + stt * k : nullptr);
+      ++k;
+    }
+    if (!rc && cfg->progress && cfg->progress(it + 1, total, cfg->progress_user)) {
+      set_error("interrupted by the progress callback at sweep %d", it + 1);
+      rc = GPIRT_ERR_INTERRUPT;
+    }
+  }
+  if (out) {
+    int rc2 = gpirt_sampler_diagnostics(s, out);
+    if (!rc) rc = rc2;
+    out->seconds_total =
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  gpirt_sampler_destroy(s);
+  return rc;
+}
+
+// ---- parity entry points --------------------------------------------------------------------
+
+int gpirt_k_build(const double *x, int32_t n, double ls, double sf, double jitter, double *K) {
+  if (!x || !K || n < 1) { set_error("gpirt_k_build: bad argument"); return GPIRT_ERR_BAD_ARG; }
+  GP_TRY(have_device());
+  const int np = (int)pad_up(n);
+  DevBuf dx, dS;
+  GP_TRY(dx.alloc(sizeof(double) * n));
+  GP_TRY(dS.alloc(sizeof(double) * (size_t)np * np, false));
+  GP_HIP(hipMemcpy(dx.p, x, sizeof(double) * n, hipMemcpyHostToDevice));
+  GP_TRY(launch_k_build(0, dx.as<double>(), 0, n, np, 1, ls, sf, jitter, dS.as<double>(), true));
+  GP_TRY(download_padded(K, n, n, dS.as<double>(), np, 0));
+  GP_HIP(hipDeviceSynchronize());
+  return GPIRT_OK;
+}
+
+// upload an n x n matrix into a padded buffer whose pad block is the identity
+static int upload_spd_padded(const double *S, int n, int np, double *d) {
+  GP_HIP(hipMemset(d, 0, sizeof(double) * (size_t)np * np));
+  GP_TRY(upload_padded(S, n, n, d, np, 0));
+  if (np > n) {
+    std::vector<double> ones(np - n, 1.0);
+    GP_HIP(hipMemcpy2D(d + (size_t)n * (np + 1), sizeof(double) * (np + 1), ones.data(),
+                       sizeof(double), sizeof(double), np - n, hipMemcpyHostToDevice));
+  }
+  return GPIRT_OK;
+}
+
+int gpirt_potrf(const double *S, int32_t n, double *L) {
+  if (!S || !L || n < 1) { set_error("gpirt_potrf: bad argument"); return GPIRT_ERR_BAD_ARG; }
+  GP_TRY(have_device());
+  const int np = (int)pad_up(n), nb = np / TILE;
+  DevBuf dS, dI, dinfo;
+  GP_TRY(dS.alloc(sizeof(double) * (size_t)np * np, false));
+  GP_TRY(dI.alloc(sizeof(double) * (size_t)TILE * TILE * nb));
+  GP_TRY(dinfo.alloc(sizeof(int)));
+  GP_TRY(upload_spd_padded(S, n, np, dS.as<double>()));
+  GP_TRY(launch_potrf(0, dS.as<double>(), np, 1, dI.as<double>(), dinfo.as<int>()));
+  int info = 0;
+  GP_HIP(hipMemcpy(&info, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
+  GP_TRY(download_padded(L, n, n, dS.as<double>(), np, 0));
+  GP_HIP(hipDeviceSynchronize());
+  for (int j = 1; j < n; ++j)
+    for (int i = 0; i < j; ++i) L[i + (size_t)n * j] = 0.0;
+  if (info) { set_error("gpirt_potrf: pivot %d is not positive", info); return GPIRT_ERR_NOT_PD; }
+  return GPIRT_OK;
+}
+
+int gpirt_trmm_lz(const double *L, const double *Z, int32_t n, int32_t k, double *N) {
+  if (!L || !Z || !N || n < 1 || k < 1) { set_error("gpirt_trmm_lz: bad argument"); return GPIRT_ERR_BAD_ARG; }
+  GP_TRY(have_device());
+  const int np = (int)pad_up(n), kp = (int)pad_up(k);
+  DevBuf dL, dZ, dN;
+  GP_TRY(dL.alloc(sizeof(double) * (size_t)np * np));
+  GP_TRY(dZ.alloc(sizeof(double) * (size_t)np * kp));
+  GP_TRY(dN.alloc(sizeof(double) * (size_t)np * kp));
+  GP_TRY(upload_padded(L, n, n, dL.as<double>(), np, 0));
+  GP_TRY(upload_padded(Z, n, k, dZ.as<double>(), np, 0));
+  GemmArgs g{};
+  g.A = dL.as<double>(); g.lda = np; g.B = dZ.as<double>(); g.ldb = np; g.C = dN.as<double>();
+  g.ldc = np; g.M = np; g.N = kp; g.K = np; g.batch = 1; g.alpha = 1.0; g.beta = 0.0; g.k_trim = 1;
+  GP_TRY(launch_gemm(0, false, false, g));
+  GP_TRY(download_padded(N, n, k, dN.as<double>(), np, 0));
+  GP_HIP(hipDeviceSynchronize());
+  return GPIRT_OK;
+}
+
+// device factor + diagonal-block inverses from a host factor (re-derives the inverses by
+// factoring L L^T's diagonal blocks is not possible without S, so S = L L^T is rebuilt)
+static int factor_from_host_L(const double *L, int n, int np, DevBuf &dS, DevBuf &dI) {
+  const int nb = np / TILE;
+  DevBuf dL, dinfo;
+  GP_TRY(dL.alloc(sizeof(double) * (size_t)np * np));
+  GP_TRY(dS.alloc(sizeof(double) * (size_t)np * np));
+  GP_TRY(dI.alloc(sizeof(double) * (size_t)TILE * TILE * nb));
+  GP_TRY(dinfo.alloc(sizeof(int)));
+  GP_TRY(upload_spd_padded(L, n, np, dL.as<double>()));
+  GemmArgs g{};  // S = L L^T
+  g.A = dL.as<double>(); g.lda = np; g.B = dL.as<double>(); g.ldb = np; g.C = dS.as<double>();
+  g.ldc = np; g.M = np; g.N = np; g.K = np; g.batch = 1; g.alpha = 1.0; g.beta = 0.0;
+  GP_TRY(launch_gemm(0, false, true, g));
+  GP_TRY(launch_potrf(0, dS.as<double>(), np, 1, dI.as<double>(), dinfo.as<int>()));
+  int info = 0;
+  GP_HIP(hipMemcpy(&info, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (info) { set_error("L L^T is not positive definite (pivot %d)", info); return GPIRT_ERR_NOT_PD; }
+  return GPIRT_OK;
+}
+
+int gpirt_potrs(const double *L, const double *B, int32_t n, int32_t k, double *X) {
+  if (!L || !B || !X || n < 1 || k < 1) { set_error("gpirt_potrs: bad argument"); return GPIRT_ERR_BAD_ARG; }
+  GP_TRY(have_device());
+  const int np = (int)pad_up(n), kp = (int)pad_up(k);
+  DevBuf dS, dI, dB;
+  GP_TRY(factor_from_host_L(L, n, np, dS, dI));
+  GP_TRY(dB.alloc(sizeof(double) * (size_t)np * kp));
+  GP_TRY(upload_padded(B, n, k, dB.as<double>(), np, 0));
+  GP_TRY(launch_potrs(0, dS.as<double>(), dI.as<double>(), np, 1, dB.as<double>(), np, 0, kp));
+  GP_TRY(download_padded(X, n, k, dB.as<double>(), np, 0));
+  GP_HIP(hipDeviceSynchronize());
+  return GPIRT_OK;
+}
+
+int gpirt_ordinal_loglik(const double *g, const int8_t *y, const double *b, int32_t n, int32_t u,
+                         int32_t C, double *ll_unit, double *ll_row) {
+  if (!g || !y || !b || n < 1 || u < 1 || C < 2 || C > MAXC) {
+    set_error("gpirt_ordinal_loglik: bad argument");
+    return GPIRT_ERR_BAD_ARG;
+  }
+  GP_TRY(have_device());
+  DevBuf dg, dy, db, dlu, dlr;
+  GP_TRY(dg.alloc(sizeof(double) * (size_t)n * u));
+  GP_TRY(dy.alloc((size_t)n * u));
+  GP_TRY(db.alloc(sizeof(double) * (size_t)(C + 1) * u));
+  GP_TRY(dlu.alloc(sizeof(double) * u));
+  GP_TRY(dlr.alloc(sizeof(double) * n));
+  GP_HIP(hipMemcpy(dg.p, g, sizeof(double) * (size_t)n * u, hipMemcpyHostToDevice));
+  GP_HIP(hipMemcpy(dy.p, y, (size_t)n * u, hipMemcpyHostToDevice));
+  GP_HIP(hipMemcpy(db.p, b, sizeof(double) * (size_t)(C + 1) * u, hipMemcpyHostToDevice));
+  GP_TRY(launch_loglik(0, dg.as<double>(), n, dy.as<int8_t>(), n, db.as<double>(), n, u, C,
+                       ll_unit ? dlu.as<double>() : nullptr, ll_row ? dlr.as<double>() : nullptr));
+  if (ll_unit) GP_HIP(hipMemcpy(ll_unit, dlu.p, sizeof(double) * u, hipMemcpyDeviceToHost));
+  if (ll_row) GP_HIP(hipMemcpy(ll_row, dlr.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+  GP_HIP(hipDeviceSynchronize());
+  return GPIRT_OK;
+}
+
+int gpirt_ess_f(double *f, const double *nu, const double *mu, const int8_t *y, const double *b,
+                const double *unif, int32_t n, int32_t u, int32_t C, int32_t max_rounds,
+                int32_t *rounds, double *ll) {
+  if (!f || !nu || !y || !b || !unif || n < 1 || u < 1 || C < 2 || C > MAXC || max_rounds < 0) {
+    set_error("gpirt_ess_f: bad argument");
+    return GPIRT_ERR_BAD_ARG;
+  }
+  GP_TRY(have_device());
+  const size_t nu_ = (size_t)n * u;
+  DevBuf df, dn, dm, dy, db, du, dr, dl;
+  GP_TRY(df.alloc(sizeof(double) * nu_)); GP_TRY(dn.alloc(sizeof(double) * nu_));
+  GP_TRY(dm.alloc(sizeof(double) * nu_)); GP_TRY(dy.alloc(nu_));
+  GP_TRY(db.alloc(sizeof(double) * (size_t)(C + 1) * u));
+  GP_TRY(du.alloc(sizeof(double) * (size_t)(max_rounds + 2) * u));
+  GP_TRY(dr.alloc(sizeof(int32_t) * u)); GP_TRY(dl.alloc(sizeof(double) * u));
+  GP_HIP(hipMemcpy(df.p, f, sizeof(double) * nu_, hipMemcpyHostToDevice));
+  GP_HIP(hipMemcpy(dn.p, nu, sizeof(double) * nu_, hipMemcpyHostToDevice));
+  if (mu) GP_HIP(hipMemcpy(dm.p, mu, sizeof(double) * nu_, hipMemcpyHostToDevice));
+  GP_HIP(hipMemcpy(dy.p, y, nu_, hipMemcpyHostToDevice));
+  GP_HIP(hipMemcpy(db.p, b, sizeof(double) * (size_t)(C + 1) * u, hipMemcpyHostToDevice));
+  GP_HIP(hipMemcpy(du.p, unif, sizeof(double) * (size_t)(max_rounds + 2) * u, hipMemcpyHostToDevice));
+  EssFArgs a{};
+  a.f = df.as<double>(); a.nu = dn.as<double>(); a.ld = n; a.mu = dm.as<double>(); a.ld_mu = n;
+  a.y = dy.as<int8_t>(); a.ldy = n; a.bthr = db.as<double>(); a.unif = du.as<double>();
+  a.Np = n; a.U_pad = u; a.C = C; a.mloc = u; a.ML = u; a.m = u; a.R = max_rounds;
+  a.rounds = dr.as<int32_t>(); a.ll = dl.as<double>();
+  GP_TRY(launch_ess_f(0, a));
+  GP_HIP(hipMemcpy(f, df.p, sizeof(double) * nu_, hipMemcpyDeviceToHost));
+  if (rounds) GP_HIP(hipMemcpy(rounds, dr.p, sizeof(int32_t) * u, hipMemcpyDeviceToHost));
+  if (ll) GP_HIP(hipMemcpy(ll, dl.p, sizeof(double) * u, hipMemcpyDeviceToHost));
+  GP_HIP(hipDeviceSynchronize());
+  return GPIRT_OK;
+}
+
+int gpirt_fstar_predict(const double *x, const double *L, const double *f, int32_t n, int32_t u,
+                        double ls, double sf, int32_t n_grid, double grid_lo, double grid_step,
+                        double *fstar) {
+  if (!x || !L || !f || !fstar || n < 1 || u < 1 || n_grid < 1) {
+    set_error("gpirt_fstar_predict: bad argument");
+    return GPIRT_ERR_BAD_ARG;
+  }
+  GP_TRY(have_device());
+  const int np = (int)pad_up(n), up = (int)pad_up(u), gp = (int)pad_up(n_grid);
+  DevBuf dS, dI, dx, dW, dF, dGt, dout;
+  GP_TRY(factor_from_host_L(L, n, np, dS, dI));
+  GP_TRY(dx.alloc(sizeof(double) * n));
+  GP_TRY(dW.alloc(sizeof(double) * (size_t)np * gp));
+  GP_TRY(dF.alloc(sizeof(double) * (size_t)np * up));
+  GP_TRY(dGt.alloc(sizeof(double) * (size_t)up * gp));
+  GP_TRY(dout.alloc(sizeof(double) * (size_t)n_grid * u));
+  GP_HIP(hipMemcpy(dx.p, x, sizeof(double) * n, hipMemcpyHostToDevice));
+  GP_TRY(upload_padded(f, n, u, dF.as<double>(), np, 0));
+  GP_TRY(launch_kstar_t(0, dx.as<double>(), 0, n, np, 1, ls, sf, n_grid, gp, grid_lo, grid_step,
+                        dW.as<double>()));
+  GP_TRY(launch_potrs(0, dS.as<double>(), dI.as<double>(), np, 1, dW.as<double>(), np, 0, gp));
+  GemmArgs g{};
+  g.A = dF.as<double>(); g.lda = np; g.B = dW.as<double>(); g.ldb = np; g.C = dGt.as<double>();
+  g.ldc = up; g.M = up; g.N = gp; g.K = np; g.batch = 1; g.alpha = 1.0; g.beta = 0.0;
+  GP_TRY(launch_gemm(0, true, false, g));
+  GP_TRY(launch_export_fstar(0, dGt.as<double>(), up, n_grid, 1, u, up, dout.as<double>()));
+  GP_HIP(hipMemcpy(fstar, dout.p, sizeof(double) * (size_t)n_grid * u, hipMemcpyDeviceToHost));
+  GP_HIP(hipDeviceSynchronize());
+  return GPIRT_OK;
+}
+
+static int rng_entry(uint64_t seed, uint32_t tag, uint32_t sweep, uint32_t unit, int64_t count,
+                     int normal, double *out) {
+  if (!out || count < 0) { set_error("gpirt_rng: bad argument"); return GPIRT_ERR_BAD_ARG; }
+  GP_TRY(have_device());
+  DevBuf d;
+  GP_TRY(d.alloc(sizeof(double) * (size_t)count));
+  GP_TRY(launch_rng_fill(0, seed, tag, sweep, unit, count, normal, d.as<double>()));
+  GP_HIP(hipMemcpy(out, d.p, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
+  return GPIRT_OK;
+}
+
+int gpirt_rng_normal(uint64_t seed, uint32_t tag, uint32_t sweep, uint32_t unit, int64_t count,
+                     double *out) {
+  return rng_entry(seed, tag, sweep, unit, count, 1, out);
+}
+
+int gpirt_rng_uniform(uint64_t seed, uint32_t tag, uint32_t sweep, uint32_t unit, int64_t count,
+                      double *out) {
+  return rng_entry(seed, tag, sweep, unit, count, 0, out);
+}
+
+}  // extern "C"

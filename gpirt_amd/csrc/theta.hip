@@ -1,0 +1,198 @@
+// Respondent step and the state snap.
+//
+// Each respondent's trajectory theta_i[1..H] gets one elliptical-slice update
+// (utils/elliptical_slice.m:47-102) under the temporal GP prior, with the likelihood read
+// off the grid: f* is looked up at the nearest grid point (the index rule of main.m:69) and
+// the ordinal-probit cell of log_like_fn.m:3-4 / gpirt-sythetic.R:159-167 is summed over
+// this rank's items.  All respondents advance in lock-step rounds so that, when items are
+// sharded over GPUs, one n-vector sum-all-reduce per round is the only exchange.
+#include "kernels.h"
+
+namespace gpirt {
+
+__device__ inline int grid_index(double x, double lo, double step, int G) {
+  double r = rint((x - lo) / step);
+  if (!(r > 0.0)) return 0;
+  if (r > (double)(G - 1)) return G - 1;
+  return (int)r;
+}
+
+__device__ inline double prior_mean(const double *tpm, int i, int h) {
+  return tpm[2 * i] + tpm[2 * i + 1] * (double)(h + 1);
+}
+
+// ellipse draw nu_i = L_t z + s0 z_H + s1 t z_{H+1}, centred state x_i = theta_i - mean_i
+__global__ void theta_prepare_kernel(ThetaArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int H = a.H, n = a.n;
+  double z[MAXH + 2];
+  for (int k = 0; k < H + 2; ++k) z[k] = rng_normal_at(a.seed, TAG_T_Z, a.sweep, (uint32_t)i, (uint32_t)k);
+  const double s0 = a.tps[2 * i], s1 = a.tps[2 * i + 1];
+  for (int h = 0; h < H; ++h) {
+    double t = (double)(h + 1);
+    double acc = s0 * z[H] + s1 * t * z[H + 1];
+    for (int k = 0; k <= h; ++k) acc += a.Lt[h + H * k] * z[k];
+    a.nu[i + (int64_t)n * h] = acc;
+    a.xc[i + (int64_t)n * h] = a.theta[i + (int64_t)n * h] - prior_mean(a.tpm, i, h);
+  }
+  a.done[i] = 0;
+}
+
+int launch_theta_prepare(hipStream_t st, const ThetaArgs &a) {
+  hipLaunchKernelGGL(theta_prepare_kernel, dim3((a.n + 127) / 128), dim3(128), 0, st, a);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// local-items log-likelihood of every active respondent, one wave per respondent
+__global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initial) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + w;
+  if (i >= a.n) return;
+  if (!initial && a.done[i]) {
+    if (lane == 0) a.buf[i] = 0.0;
+    return;
+  }
+  const int H = a.H, n = a.n, mloc = a.mloc, ML = a.ML, U_pad = a.U_pad;
+  const double *b0 = a.betaS, *b1 = a.betaS + U_pad, *b2 = a.betaS + 2 * (int64_t)U_pad;
+  double acc = 0.0;
+  for (int h = 0; h < H; ++h) {
+    double th = initial ? a.theta[i + (int64_t)n * h]
+                        : a.prop[i + (int64_t)n * h] + prior_mean(a.tpm, i, h);
+    const int g = grid_index(th, a.grid_lo, a.grid_step, a.G);
+    const double xg = a.grid_lo + a.grid_step * g;
+    const int p = a.constant_irf ? 0 : h;
+    const double *Gr = a.Gt + (int64_t)U_pad * g + (int64_t)ML * p;
+    const int8_t *yr = a.yT + (int64_t)ML * H * i + (int64_t)ML * h;
+    for (int jl = lane; jl < mloc; jl += 64) {
+      int yy = yr[jl];
+      if (yy > 0) {
+        int u = jl + ML * p;
+        double gg = Gr[jl] + b0[u] + b1[u] * xg + b2[u] * xg * xg;
+        double lo = a.bthrS[u + (int64_t)U_pad * (yy - 1)], hi = a.bthrS[u + (int64_t)U_pad * yy];
+        acc += ordinal_cell_z(lo - gg, hi - gg);
+      }
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) a.buf[i] = acc;
+}
+
+int launch_theta_eval(hipStream_t st, const ThetaArgs &a, int initial) {
+  hipLaunchKernelGGL(theta_eval_kernel, dim3((a.n + 3) / 4), dim3(256), 0, st, a, initial);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// accept / shrink (elliptical_slice.m:66-100); round 0 sets the slice height and the first
+// proposal from the log-likelihood of the current state
+__global__ void theta_decide_kernel(ThetaArgs a, int round) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int H = a.H, n = a.n;
+  double phi;
+  if (round == 0) {
+    a.hh[i] = log(rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, 0)) + a.buf[i];
+    phi = rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, 1) * kTwoPi;
+    a.pmin[i] = phi - kTwoPi;
+    a.pmax[i] = phi;
+  } else {
+    if (a.done[i]) return;
+    if (a.buf[i] > a.hh[i]) {
+      for (int h = 0; h < H; ++h)
+        a.theta[i + (int64_t)n * h] = a.prop[i + (int64_t)n * h] + prior_mean(a.tpm, i, h);
+      a.done[i] = 1;
+      return;
+    }
+    phi = a.phi[i];
+    if (phi > 0.0) a.pmax[i] = phi;
+    else if (phi < 0.0) a.pmin[i] = phi;
+    else { a.done[i] = 1; atomicAdd(&a.counters[1], 1ull); return; }
+    if (round >= a.R) { a.done[i] = 1; atomicAdd(&a.counters[1], 1ull); return; }
+    double lo = a.pmin[i], hi = a.pmax[i];
+    phi = rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, (uint32_t)(1 + round)) * (hi - lo) + lo;
+  }
+  a.phi[i] = phi;
+  double s, c;
+  sincos(phi, &s, &c);
+  for (int h = 0; h < H; ++h)
+    a.prop[i + (int64_t)n * h] = a.xc[i + (int64_t)n * h] * c + a.nu[i + (int64_t)n * h] * s;
+  atomicAdd(a.remaining, 1);
+}
+
+int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int round) {
+  hipLaunchKernelGGL(theta_decide_kernel, dim3((a.n + 127) / 128), dim3(128), 0, st, a, round);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// snap: re-anchor f at the new theta from f* (main.m:69-73).  Gt is unit-contiguous, f is
+// row-contiguous: a 64x64 tile goes through LDS so that both sides are coalesced.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void snap_kernel(const double *__restrict__ Gt, int U_pad,
+                                                   const double *__restrict__ x, int64_t x_stride,
+                                                   int Np, int mloc, int ML, int G, double lo,
+                                                   double step, double *__restrict__ f, int64_t ld) {
+  __shared__ double tile[64][65];
+  __shared__ int gidx[64];
+  const int p = blockIdx.z;
+  const int r0 = blockIdx.x * 64, u0 = blockIdx.y * 64;  // u0 within the group's mloc units
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    int r = r0 + tid;
+    gidx[tid] = r < Np ? grid_index(x[x_stride * p + r], lo, step, G) : 0;
+  }
+  __syncthreads();
+  const int ul = tid & 63;
+  for (int rl = tid >> 6; rl < 64; rl += 4) {
+    int uu = u0 + ul;
+    tile[rl][ul] = uu < mloc ? Gt[(int64_t)U_pad * gidx[rl] + (int64_t)ML * p + uu] : 0.0;
+  }
+  __syncthreads();
+  const int rl2 = tid & 63;
+  for (int ul2 = tid >> 6; ul2 < 64; ul2 += 4) {
+    int r = r0 + rl2, uu = u0 + ul2;
+    if (r < Np && uu < mloc) f[r + ld * ((int64_t)ML * p + uu)] = tile[rl2][ul2];
+  }
+}
+
+int launch_snap(hipStream_t st, const double *Gt, int U_pad, const double *x, int64_t x_stride,
+                int Np, int P, int mloc, int ML, int G, double lo, double step, double *f,
+                int64_t ld) {
+  dim3 grid((Np + 63) / 64, (mloc + 63) / 64, P);
+  hipLaunchKernelGGL(snap_kernel, grid, dim3(256), 0, st, Gt, U_pad, x, x_stride, Np, mloc, ML, G, lo,
+                     step, f, ld);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+__global__ __launch_bounds__(256) void export_fstar_kernel(const double *__restrict__ Gt, int U_pad,
+                                                           int G, int mloc, int ML,
+                                                           double *__restrict__ out) {
+  __shared__ double tile[64][65];
+  const int p = blockIdx.z;
+  const int g0 = blockIdx.x * 64, u0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int ul = tid & 63;
+  for (int gl = tid >> 6; gl < 64; gl += 4) {
+    int g = g0 + gl, u = u0 + ul;
+    tile[gl][ul] = (g < G && u < mloc) ? Gt[u + (int64_t)ML * p + (int64_t)U_pad * g] : 0.0;
+  }
+  __syncthreads();
+  const int gl2 = tid & 63;
+  for (int ul2 = tid >> 6; ul2 < 64; ul2 += 4) {
+    int g = g0 + gl2, u = u0 + ul2;
+    if (g < G && u < mloc) out[g + (int64_t)G * (u + (int64_t)mloc * p)] = tile[gl2][ul2];
+  }
+}
+
+int launch_export_fstar(hipStream_t st, const double *Gt, int U_pad, int G, int P, int mloc, int ML,
+                        double *out) {
+  dim3 grid((G + 63) / 64, (mloc + 63) / 64, P);
+  hipLaunchKernelGGL(export_fstar_kernel, grid, dim3(256), 0, st, Gt, U_pad, G, mloc, ML, out);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+}  // namespace gpirt

@@ -1,0 +1,44 @@
+"""Plumbing for one-process-per-GPU runs: item partitioning and the all-reduce hook that
+the respondent step calls once per proposal round.  ``torch.distributed`` (backend "nccl",
+which is RCCL on ROCm, or "gloo" for CPU rehearsals) carries the collective; nothing else
+in the package depends on torch."""
+import ctypes as C
+
+import numpy as np
+
+
+def item_range(m, rank, world):
+    """Contiguous, balanced split of items 0..m-1: rank r owns [begin, end)."""
+    base, extra = divmod(m, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+class _DevVec:
+    """Zero-copy view of `count` doubles at a device address for torch.as_tensor."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {
+            "shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2,
+            "strides": None}
+
+
+def torch_allreduce(group=None, device_buffers=True):
+    """Return ``f(ptr, count) -> 0`` summing `count` doubles at `ptr` over the process group,
+    in place.  `device_buffers=True`: `ptr` is HBM on the current device (HIP backend);
+    False: `ptr` is host memory (CPU rehearsal with gloo)."""
+    import torch
+    import torch.distributed as dist
+
+    def hook(ptr, count):
+        if device_buffers:
+            t = torch.as_tensor(_DevVec(ptr, count), device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.current_stream().synchronize()
+        else:
+            arr = np.ctypeslib.as_array((C.c_double * count).from_address(ptr))
+            t = torch.from_numpy(arr)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return 0
+
+    return hook

@@ -1,0 +1,241 @@
+/*
+ * gpirt.h -- plain C ABI of the MI355X-native GPIRT Gibbs sweep.
+ *
+ * This is the boundary an R `.Call` shim (or any other FFI: ctypes, cgo, JNI)
+ * binds.  It replaces the R-level call
+ *     gpirtMCMC(data, sample_iterations, burn_iterations, THIN, CHAIN, ...)
+ * made by the reference drivers (gpirt-sythetic.R:88-94, gpirt-senate.R:77-81,
+ * TAPS/gpirt_TAPS.R:30-36, VAA/gpirt_VAA.R:137-145), whose sampler lives in an
+ * external Rcpp package; the in-tree statement of the same sweep is the MATLAB
+ * prototype main.m:46-87 + utils/{elliptical_slice,sample_fs,log_like_fn,
+ * sigmoid_fn,sample_score,model}.m.
+ *
+ * Conventions
+ *   - No C++ types, no torch types, no exceptions cross this boundary.
+ *   - Every array is column-major (R order).  `data[n,m,H]` element (i,j,h) is
+ *     at i + n*(j + m*h).
+ *   - The caller owns every buffer it passes.  The library never frees caller
+ *     memory and returns no library-owned pointer except static strings.
+ *   - Every function returns GPIRT_OK (0) or a negative gpirt_status; the text
+ *     of the last failure on the calling thread is gpirt_last_error().
+ *   - Pointers named `h_*`/unprefixed are HOST pointers; `d_*` are DEVICE
+ *     pointers (hipMalloc memory on the current device).
+ */
+#ifndef GPIRT_H
+#define GPIRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPIRT_VERSION_MAJOR 0
+#define GPIRT_VERSION_MINOR 1
+
+typedef enum gpirt_status {
+  GPIRT_OK = 0,
+  GPIRT_ERR_BAD_ARG = -1,     /* bad shape / null pointer / unsupported option   */
+  GPIRT_ERR_NOT_PD = -2,      /* Cholesky failed even after jitter escalation    */
+  GPIRT_ERR_ESS_COLLAPSE = -3,/* slice bracket shrank to the current point
+                                 (utils/elliptical_slice.m:96-98 raises here)    */
+  GPIRT_ERR_HIP = -4,         /* a HIP runtime call failed                       */
+  GPIRT_ERR_COMM = -5,        /* the collective (RCCL or callback) failed        */
+  GPIRT_ERR_NO_DEVICE = -6,   /* no gfx950 device visible                        */
+  GPIRT_ERR_INTERRUPT = -7    /* the progress callback asked to stop             */
+} gpirt_status;
+
+/* KERNEL argument of gpirtMCMC ("RBF" gpirt-sythetic.R:93, "Matern" TAPS/onerun:23):
+ * temporal kernel of the respondent trajectories. */
+typedef enum gpirt_kernel { GPIRT_KERNEL_RBF = 0, GPIRT_KERNEL_MATERN52 = 1 } gpirt_kernel;
+
+/* How the respondent step draws theta. */
+typedef enum gpirt_theta_mode {
+  GPIRT_THETA_ESS = 0,  /* elliptical slice over each respondent's H-vector under the
+                           temporal GP prior, likelihood by grid lookup into f*       */
+  GPIRT_THETA_GRID = 1  /* inverse-CDF draw on the grid (utils/sample_score.m:4-19);
+                           H = 1 only                                                 */
+} gpirt_theta_mode;
+
+enum {
+  GPIRT_RETURN_F = 1,      /* copy each kept draw of f back (large: n*m*H doubles per draw) */
+  GPIRT_RETURN_FSTAR = 2   /* copy each kept draw of f* back (n_grid*m*P doubles per draw)  */
+};
+
+/* Sum-all-reduce hook used by the respondent step when items are sharded over
+ * ranks: must leave, in place, the element-wise sum over all ranks of `count`
+ * doubles at `buf` on every rank.  `buf` is a DEVICE pointer for the HIP
+ * backend and a host pointer for the CPU oracle.  Return 0 on success. */
+typedef int (*gpirt_allreduce_fn)(double *buf, int64_t count, void *user);
+
+/* Called once per finished sweep on the calling thread (the place for
+ * R_CheckUserInterrupt); a non-zero return aborts with GPIRT_ERR_INTERRUPT. */
+typedef int (*gpirt_progress_fn)(int32_t sweep, int32_t total_sweeps, void *user);
+
+/* Named arguments of gpirtMCMC (union over the reference's call sites) plus the
+ * knobs the reference hard-codes.  Zero-initialise, then call
+ * gpirt_config_defaults(). */
+typedef struct gpirt_config {
+  int32_t struct_size;        /* = sizeof(gpirt_config), ABI check                         */
+  int32_t n;                  /* respondents                                               */
+  int32_t m;                  /* items (GLOBAL count, also when sharded)                   */
+  int32_t H;                  /* periods (horizon)                                         */
+  int32_t C;                  /* response categories; data values are 1..C, 0 = missing    */
+  int32_t sample_iterations;  /* gpirt-sythetic.R:60                                       */
+  int32_t burn_iterations;    /* gpirt-sythetic.R:61                                       */
+  int32_t thin;               /* THIN, gpirt-sythetic.R:75                                 */
+  int32_t chain;              /* chain index 0..CHAIN-1; independent stream per chain      */
+  uint64_t seed;              /* SEED                                                      */
+  double theta_os;            /* temporal output scale   (gpirt-sythetic.R:62-73)          */
+  double theta_ls;            /* temporal length scale; <= 0 => constant over time
+                                 (gpirt-senate.R:22-28)                                    */
+  int32_t kernel;             /* gpirt_kernel                                              */
+  int32_t constant_irf;       /* 1: one IRF per item shared by all periods
+                                 (TAPS/gpirt_TAPS.R:36)                                    */
+  double jitter;              /* added to diag K(theta,theta); 1e-6 (generate_data.R:55)   */
+  double irf_ls;              /* IRF kernel length scale, 1 (utils/model.m:6)              */
+  double irf_sf;              /* IRF kernel signal sd, 1     (utils/model.m:6)             */
+  int32_t n_grid;             /* 1001: xs = seq(-5,5,0.01) (gpirt-sythetic.R:113)          */
+  double grid_lo;             /* -5                                                        */
+  double grid_step;           /* 0.01                                                      */
+  int32_t theta_mode;         /* gpirt_theta_mode                                          */
+  int32_t max_ess_rounds;     /* cap on shrink rounds per slice update (0 => 200)          */
+  int32_t flags;              /* GPIRT_RETURN_*                                            */
+  int32_t item_begin;         /* this rank owns global items [item_begin, item_end)        */
+  int32_t item_end;           /* 0,0 => all items                                          */
+  int32_t rank;
+  int32_t world;              /* number of ranks sharing the chain (1 => no collective)    */
+  gpirt_allreduce_fn allreduce; /* required when world > 1                                 */
+  void *allreduce_user;
+  gpirt_progress_fn progress; /* optional                                                  */
+  void *progress_user;
+} gpirt_config;
+
+/* Caller-allocated output buffers; any pointer may be NULL to skip that output.
+ * K = sample_iterations / thin kept draws, m_loc = item_end - item_begin,
+ * P = constant_irf ? 1 : H.  The draw index is the slowest dimension. */
+typedef struct gpirt_outputs {
+  double *theta;      /* [n, H, K]                 samples$theta (gpirt-sythetic.R:123)        */
+  double *f;          /* [n, m_loc, H, K]          samples$f, non-linear residual (:153)       */
+  double *fstar;      /* [n_grid, m_loc, P, K]     samples$fstar on the grid (:154)            */
+  double *beta;       /* [3, m_loc, P, K]          samples$beta (:153)                         */
+  double *threshold;  /* [m_loc, C+1, P, K]        samples$threshold, +-Inf ends (:193)        */
+  double *loglik;     /* [sample+burn]             local-items log-likelihood after each sweep */
+  /* diagnostics (totals over the whole run) */
+  int64_t ess_f_rounds;       /* likelihood evaluations spent in the f step             */
+  int64_t ess_param_rounds;   /* ... in the beta/threshold step                         */
+  int64_t ess_theta_rounds;   /* ... in the respondent step (lock-step rounds)          */
+  int64_t ess_capped;         /* slice updates that hit max_ess_rounds (state kept)     */
+  int32_t jitter_retries;     /* Cholesky retries with 10x jitter                       */
+  int32_t reserved;
+  double seconds_total;       /* wall time inside the sweep loop                        */
+} gpirt_outputs;
+
+/* ---- library -------------------------------------------------------------------- */
+
+/* "gpirt-hip <major>.<minor> (gfx950)" -- static string. */
+const char *gpirt_version(void);
+/* Text of the last failure on this thread -- static thread-local buffer. */
+const char *gpirt_last_error(void);
+/* Number of visible HIP devices (0 when there is no GPU or no driver). */
+int gpirt_device_count(void);
+/* Select the device used by every later call on this thread. */
+int gpirt_set_device(int device);
+/* Fill `cfg` with the reference's defaults (gpirt-sythetic.R:60-94, utils/model.m:6). */
+void gpirt_config_defaults(gpirt_config *cfg);
+
+/* ---- the drop-in: one chain of gpirtMCMC ------------------------------------------
+ * Replaces gpirtMCMC(...)[[chain]] (gpirt-sythetic.R:88-94); the sweep follows
+ * main.m:46-87 generalised to ordinal probit / thresholds / dynamic theta as the R
+ * call sites require.
+ *   y                  int8 [n, m, H], 1..C, 0 = NA           (`data`)
+ *   theta_init         [n, H] or NULL (=> N(0,1) draws)       (`theta_init`)
+ *   beta_prior_means   [3, m] or NULL (=> 0)
+ *   beta_prior_sds     [3, m] or NULL (=> 1); 0 switches a term off (TAPS/gpirt_TAPS.R:28-29)
+ *   theta_prior_means  [2, n] or NULL (=> 0)   constant / linear-trend mean
+ *   theta_prior_sds    [2, n] or NULL (=> 0)   constant / linear-trend sd
+ *   thresholds         [C+1] fixed thresholds (first/last ignored, treated as -+Inf),
+ *                      or NULL => sampled per (item, period) (gpirt-sythetic.R:94)
+ * All prior arrays index GLOBAL items.  y holds all m items; a sharded rank reads
+ * only its own columns. */
+int gpirt_run(const gpirt_config *cfg, const int8_t *y, const double *theta_init,
+              const double *beta_prior_means, const double *beta_prior_sds,
+              const double *theta_prior_means, const double *theta_prior_sds,
+              const double *thresholds, gpirt_outputs *out);
+
+/* ---- resident sampler (what gpirt_run is built from) ---------------------------------
+ * Keeps y, theta, f, L, ... in HBM between calls so that a caller (the benchmark, an
+ * interactive R session) can advance the chain without re-uploading anything. */
+typedef struct gpirt_sampler gpirt_sampler;
+
+int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double *theta_init,
+                         const double *beta_prior_means, const double *beta_prior_sds,
+                         const double *theta_prior_means, const double *theta_prior_sds,
+                         const double *thresholds, gpirt_sampler **out);
+/* Advance `sweeps` Gibbs sweeps (main.m:46-87 body).  Asynchronous work is drained
+ * before return. */
+int gpirt_sampler_sweep(gpirt_sampler *s, int32_t sweeps);
+/* Copy the current state to host buffers (any may be NULL):
+ * theta [n,H]; f [n,m_loc,H]; fstar [n_grid,m_loc,P]; beta [3,m_loc,P];
+ * threshold [m_loc,C+1,P]. */
+int gpirt_sampler_get_state(gpirt_sampler *s, double *theta, double *f, double *fstar,
+                            double *beta, double *threshold);
+/* Per-phase device time accumulated since creation (ms) and launch counts, for the
+ * roofline report.  Phases: 0 k_build, 1 potrf, 2 nu=L*Z (incl. normal draws),
+ * 3 ess_f, 4 ess_param, 5 fstar solves+gemm, 6 theta step, 7 snap.
+ * ms[8], count[8]. */
+int gpirt_sampler_phase_times(gpirt_sampler *s, double *ms, int64_t *count);
+/* Diagnostics so far: fills the counters of `out` (buffers untouched). */
+int gpirt_sampler_diagnostics(gpirt_sampler *s, gpirt_outputs *out);
+/* The HIP stream every kernel of this sampler is launched on (as a void*). */
+void *gpirt_sampler_stream(gpirt_sampler *s);
+void gpirt_sampler_destroy(gpirt_sampler *s);
+
+/* ---- deterministic kernels with injected randomness (parity-test entry points) --------
+ * Host pointers in, host pointers out; each call uploads, runs the same device
+ * kernels gpirt_sampler_sweep uses, and downloads. */
+
+/* K = sf^2 exp(-(x_i-x_j)^2 / (2 ls^2)) + jitter*I   (covSEiso at main.m:29,67;
+ * SEKernel getprob_gpirt.R:41-51).  x[n] -> K[n,n] full symmetric. */
+int gpirt_k_build(const double *x, int32_t n, double ls, double sf, double jitter, double *K);
+/* Lower Cholesky factor of S[n,n] (chol inside mvnrnd, utils/sample_fs.m:2;
+ * chol(K) idiom generate_data.R:56).  L[n,n], strict upper triangle zeroed.
+ * Returns GPIRT_ERR_NOT_PD when a pivot is not positive. */
+int gpirt_potrf(const double *S, int32_t n, double *L);
+/* N = L * Z for all columns at once (nu = prior'*randn, utils/elliptical_slice.m:64).
+ * L[n,n] lower, Z[n,k] -> N[n,k]. */
+int gpirt_trmm_lz(const double *L, const double *Z, int32_t n, int32_t k, double *N);
+/* X = S^-1 B given the Cholesky factor (the solve inside gp(...), main.m:57-58).
+ * L[n,n], B[n,k] -> X[n,k]. */
+int gpirt_potrs(const double *L, const double *B, int32_t n, int32_t k, double *X);
+/* Ordinal-probit log-likelihood (log_like_fn.m:3-4 generalised per
+ * gpirt-sythetic.R:159-167).  g[n,u] latent incl. mean, y[n,u] int8, b[C+1,u]
+ * thresholds (ends ignored) -> per-unit sums ll_unit[u] and per-row sums ll_row[n]
+ * (either may be NULL). */
+int gpirt_ordinal_loglik(const double *g, const int8_t *y, const double *b, int32_t n,
+                         int32_t u, int32_t C, double *ll_unit, double *ll_row);
+/* One elliptical-slice update per unit with injected randomness
+ * (utils/elliptical_slice.m:47-102).  f[n,u] in/out, nu[n,u], mu[n,u] fixed mean added
+ * inside the likelihood, y[n,u], b[C+1,u], unif[max_rounds+2,u] (row 0: slice height,
+ * row 1: first angle, rows 2..: shrink draws).  rounds[u] out = likelihood evaluations
+ * used (negative when capped), ll[u] out = log-likelihood of the returned f. */
+int gpirt_ess_f(double *f, const double *nu, const double *mu, const int8_t *y,
+                const double *b, const double *unif, int32_t n, int32_t u, int32_t C,
+                int32_t max_rounds, int32_t *rounds, double *ll);
+/* f* = K(xs, x) S^-1 f on the grid (gp(...) posterior mean, main.m:57-58).
+ * x[n], L[n,n] factor of K(x,x)+jitter, f[n,u] -> fstar[n_grid,u]. */
+int gpirt_fstar_predict(const double *x, const double *L, const double *f, int32_t n,
+                        int32_t u, double ls, double sf, int32_t n_grid, double grid_lo,
+                        double grid_step, double *fstar);
+/* The counter-based generator both backends share: `count` standard normals /
+ * uniforms(0,1) of stream (seed, tag, sweep, unit). */
+int gpirt_rng_normal(uint64_t seed, uint32_t tag, uint32_t sweep, uint32_t unit,
+                     int64_t count, double *out);
+int gpirt_rng_uniform(uint64_t seed, uint32_t tag, uint32_t sweep, uint32_t unit,
+                      int64_t count, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPIRT_H */

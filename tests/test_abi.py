@@ -1,0 +1,66 @@
+"""The C-ABI library loads on a machine without a GPU, exports every symbol that
+include/gpirt.h declares, and refuses to compute without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gpirt_amd import _abi, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "gpirt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(gpirt_[a-z_0-9]+)\s*\(", text)
+    return sorted(set(n for n in names if not n.endswith("_fn")))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = C.CDLL(_lib.SO_PATH)
+    decl = declared_functions()
+    assert len(decl) >= 20
+    for name in decl:
+        assert hasattr(lib, name), "libgpirt_hip.so does not export %s" % name
+        assert name in _lib.SYMBOLS, "gpirt_amd._lib does not bind %s" % name
+    assert sorted(_lib.SYMBOLS) == decl
+
+
+def test_struct_layout_matches_header_defaults():
+    lib = _lib.lib()
+    c = _abi.GpirtConfig()
+    lib.gpirt_config_defaults(C.byref(c))
+    assert c.struct_size == C.sizeof(_abi.GpirtConfig)
+    ref = _abi.default_config()
+    for name, _ in _abi.GpirtConfig._fields_:
+        if name in ("allreduce", "progress", "allreduce_user", "progress_user"):
+            continue
+        assert getattr(c, name) == getattr(ref, name), name
+    assert lib.gpirt_version().startswith(b"gpirt-hip")
+
+
+@pytest.mark.skipif(_lib.lib().gpirt_device_count() > 0, reason="a GPU is visible")
+def test_no_cpu_fallback_without_device():
+    from gpirt_amd import kernels
+    with pytest.raises(_lib.GpirtError) as e:
+        kernels.k_build(np.zeros(4))
+    assert e.value.code == _abi.GPIRT_ERR_NO_DEVICE
+    from gpirt_amd.sampler import Sampler
+    cfg = _abi.default_config(n=4, m=2, H=1, C=2)
+    with pytest.raises(_lib.GpirtError):
+        Sampler(cfg, np.ones((4, 2, 1), dtype=np.int8))
+
+
+def test_bad_arguments_are_rejected_before_touching_the_device():
+    from gpirt_amd.sampler import Sampler
+    cfg = _abi.default_config(n=4, m=2, H=1, C=99)
+    with pytest.raises(_lib.GpirtError) as e:
+        Sampler(cfg, np.ones((4, 2, 1), dtype=np.int8))
+    assert e.value.code == _abi.GPIRT_ERR_BAD_ARG
+    cfg = _abi.default_config(n=4, m=2, H=1, C=2, world=2)   # world > 1 without a hook
+    with pytest.raises(_lib.GpirtError) as e:
+        Sampler(cfg, np.ones((4, 2, 1), dtype=np.int8))
+    assert e.value.code == _abi.GPIRT_ERR_BAD_ARG

@@ -1,0 +1,214 @@
+"""GPU parity: every deterministic device kernel, called through the C ABI, against the CPU
+oracle on the same seeded inputs (tolerances stated per test), then the full sweep."""
+import numpy as np
+import pytest
+
+from gpirt_amd import _abi
+from conftest import load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from gpirt_amd import kernels
+    return kernels
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def test_library_sees_a_device():
+    from gpirt_amd import _lib
+    assert _lib.lib().gpirt_device_count() >= 1
+
+
+def test_rng_matches_oracle_stream(K, O):
+    # same Philox counters; Box-Muller differs only by libm vs device-libm rounding
+    for tag, unit in ((_abi.TAG_F_Z, 0), (_abi.TAG_T_Z, 4095)):
+        z_g = K.rng_normal(12345, tag, 7, unit, 4097)
+        z_c = O.rng_normal(12345, tag, 7, unit, 4097)
+        assert np.abs(z_g - z_c).max() < 1e-13
+    u_g = K.rng_uniform(12345, _abi.TAG_F_U, 7, 3, 1001)
+    assert np.array_equal(u_g, O.rng_uniform(12345, _abi.TAG_F_U, 7, 3, 1001))   # integer path: bit-exact
+
+
+@pytest.mark.parametrize("n", [1, 100, 128, 300])
+def test_k_build(K, O, n):
+    x = np.random.default_rng(n).normal(size=n)
+    a, b = K.k_build(x, 1.3, 0.7, 1e-6), O.k_build(x, 1.3, 0.7, 1e-6)
+    assert np.abs(a - b).max() < 1e-15      # one exp per entry
+
+
+@pytest.mark.parametrize("n", [5, 128, 300, 1000])
+def test_potrf(K, O, n):
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n))
+    S = A @ A.T + n * np.eye(n)              # well conditioned: compare factors entrywise
+    Lg, Lc = K.potrf(S), O.potrf(S)
+    assert np.abs(np.triu(Lg, 1)).max() == 0
+    assert np.abs(Lg - Lc).max() < 1e-10 * np.abs(Lc).max()
+    # the sampler's own matrix (RBF + 1e-6 I, condition ~1e9): backward error only
+    x = rng.normal(size=n)
+    Kx = O.k_build(x)
+    Lk = K.potrf(Kx)
+    assert np.abs(Lk @ Lk.T - Kx).max() < 1e-13 * n * np.abs(Kx).max()
+
+
+def test_potrf_reports_not_pd(K):
+    from gpirt_amd._lib import GpirtError
+    S = np.eye(200)
+    S[150, 150] = -1.0
+    with pytest.raises(GpirtError) as e:
+        K.potrf(S)
+    assert e.value.code == _abi.GPIRT_ERR_NOT_PD
+
+
+@pytest.mark.parametrize("n,k", [(100, 10), (300, 130), (640, 3)])
+def test_trmm_lz(K, O, n, k):
+    rng = np.random.default_rng(n + k)
+    L = np.tril(rng.normal(size=(n, n)))     # asymmetric data: catches a transposed tile map
+    Z = rng.normal(size=(n, k))
+    a, b = K.trmm_lz(L, Z), O.trmm_lz(L, Z)
+    assert np.abs(a - b).max() < 1e-12 * np.sqrt(n) * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("n,k", [(100, 7), (300, 140)])
+def test_potrs(K, O, n, k):
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n))
+    S = A @ A.T + n * np.eye(n)
+    L = O.potrf(S)
+    B = rng.normal(size=(n, k))
+    a, b = K.potrs(L, B), O.potrs(L, B)
+    assert np.abs(a - b).max() < 1e-11 * np.abs(b).max()
+    assert np.abs(S @ a - B).max() < 1e-10 * np.abs(B).max()
+
+
+@pytest.mark.parametrize("C", [2, 3, 5, 16])
+def test_ordinal_loglik(K, O, C):
+    rng = np.random.default_rng(C)
+    n, u = 1000, 37
+    b = np.zeros((C + 1, u))
+    b[1:C] = np.sort(rng.normal(size=(C - 1, u)), axis=0)
+    b[0], b[C] = -np.inf, np.inf
+    g = 3.0 * rng.normal(size=(n, u))        # reaches both tails and the floor
+    y = rng.integers(0, C + 1, size=(n, u)).astype(np.int8)
+    (lu, lr), (ou, orow) = K.ordinal_loglik(g, y, b), O.ordinal_loglik(g, y, b)
+    assert np.allclose(lu, ou, rtol=1e-12, atol=1e-10)
+    assert np.allclose(lr, orow, rtol=1e-12, atol=1e-10)
+
+
+def test_ordinal_loglik_all_missing(K):
+    b = np.array([[-np.inf], [0.0], [np.inf]])
+    lu, lr = K.ordinal_loglik(np.zeros((70, 1)), np.zeros((70, 1), dtype=np.int8), b)
+    assert lu[0] == 0 and np.all(lr == 0)
+
+
+@pytest.mark.parametrize("C,n", [(2, 100), (5, 1000)])
+def test_ess_f_injected_streams(K, O, C, n):
+    """Same f, nu, uniforms => identical accept/shrink decisions and the same new f."""
+    rng = np.random.default_rng(C * n)
+    u, R = 23, 40
+    f = rng.normal(size=(n, u)); nu = rng.normal(size=(n, u)); mu = 0.5 * rng.normal(size=(n, u))
+    y = rng.integers(0, C + 1, size=(n, u)).astype(np.int8)
+    b = np.zeros((C + 1, u)); b[1:C] = np.sort(rng.normal(size=(C - 1, u)), axis=0)
+    b[0], b[C] = -np.inf, np.inf
+    un = rng.uniform(size=(R + 2, u))
+    fg, rg, lg = K.ess_f(f, nu, mu, y, b, un, R)
+    fc, rc, lc = O.ess_f(f, nu, mu, y, b, un, R)
+    assert np.array_equal(rg, rc)
+    assert rg.max() > 1                       # the shrink branch was exercised
+    assert np.abs(fg - fc).max() < 1e-13
+    assert np.allclose(lg, lc, rtol=1e-12)
+
+
+def test_ess_f_round_cap(K, O):
+    # an impossible slice height (u0 -> log ~ 0 and a likelihood that only gets worse is not
+    # constructible in general), so cap at 1 round and check the kept state is untouched
+    rng = np.random.default_rng(9)
+    n, u, C, R = 64, 8, 2, 1
+    f = rng.normal(size=(n, u)); nu = 5 * rng.normal(size=(n, u)); mu = np.zeros((n, u))
+    y = (1 + (f > 0)).astype(np.int8)         # data agree with f: most first proposals fail
+    b = np.tile(np.array([[-np.inf], [0.0], [np.inf]]), (1, u))
+    un = np.vstack([np.full((1, u), 0.999999), rng.uniform(size=(R + 1, u))])
+    fg, rg, _ = K.ess_f(f, nu, mu, y, b, un, R)
+    fc, rc, _ = O.ess_f(f, nu, mu, y, b, un, R)
+    assert np.array_equal(rg, rc) and (rg < 0).any()
+    kept = rg < 0
+    assert np.array_equal(fg[:, kept], f[:, kept])
+
+
+def test_fstar_predict(K, O):
+    rng = np.random.default_rng(11)
+    n, u = 300, 12
+    x = rng.normal(size=n)
+    L = O.potrf(O.k_build(x, jitter=1e-4))
+    f = L @ rng.normal(size=(n, u))
+    a = K.fstar_predict(x, L, f)
+    b = O.fstar_predict(x, L, f)
+    # K + 1e-4 I has condition ~1e7: the two solve orders agree to ~cond * eps * |f|
+    assert np.abs(a - b).max() < 1e-7 * max(1.0, np.abs(b).max())
+
+
+def _pair(cfg, y, **kw):
+    from gpirt_amd.sampler import Sampler
+    from oracle import oracle
+    return Sampler(cfg, y, **kw), oracle.Sampler(cfg, y, **kw)
+
+
+@pytest.mark.parametrize("stem,C,const", [("2PL_C_2", 2, 0), ("Wiener_C_5", 5, 0), ("2PL_C_5", 5, 1)])
+def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const):
+    """Three whole sweeps from the same state with the shared generator: every accept /
+    shrink decision must coincide, so the states agree to rounding.  Tolerance 1e-5: f* goes
+    through solves with K + 1e-6 I (condition ~1e9), which bounds agreement of anything
+    downstream of it."""
+    d = load_fixture(stem)
+    y = d["y"][:, :, :4] if const else d["y"]
+    theta = d["theta"][:, :y.shape[2]]
+    n, m, H = y.shape
+    cfg = _abi.default_config(n=n, m=m, H=H, C=C, seed=5, theta_os=1.0, theta_ls=H / 2,
+                              constant_irf=const)
+    g, c = _pair(cfg, y, theta_init=theta)
+    for sweep in range(3):
+        g.sweep(1); c.sweep(1)
+        sg, sc = g.state(), c.state()
+        for k in ("theta", "beta", "f", "fstar"):
+            assert np.abs(sg[k] - sc[k]).max() < 1e-5, (sweep, k)
+        fin = np.isfinite(sc["threshold"])
+        assert np.array_equal(fin, np.isfinite(sg["threshold"]))
+        assert np.abs(sg["threshold"][fin] - sc["threshold"][fin]).max() < 1e-5
+    dg, dc = g.diagnostics(), c.diagnostics()
+    assert dg == dc
+    g.close(); c.close()
+
+
+def test_gpirtmcmc_drop_in_recovers_theta():
+    """The reference's own acceptance metric (gpirt-sythetic.R:257-260,275) on its own
+    fixture, through the gpirtMCMC mirror; and the GPU chain agrees with the CPU chain."""
+    from gpirt_amd.mcmc import gpirtMCMC
+    from oracle import oracle
+    d = load_fixture("2PL_C_2")
+    y, theta = d["y"], d["theta"]
+    n, m, H = y.shape
+    rng = np.random.default_rng(1)
+    init = theta + 0.05 * rng.normal(size=theta.shape)
+    data = np.where(y == 0, np.nan, y.astype(float))
+    res = gpirtMCMC(data, 200, 200, THIN=4, CHAIN=1, beta_prior_means=np.zeros((3, m)),
+                    beta_prior_sds=np.ones((3, m)), theta_os=1, theta_ls=H / 2, theta_init=init,
+                    KERNEL="RBF", thresholds=None, SEED=1, constant_IRF=0)[0]
+    assert res["theta"].shape == (50, n, H) and res["fstar"].shape == (50, 1001, m, H)
+    assert res["beta"].shape == (50, 3, m, H) and res["threshold"].shape == (50, m, 3, H)
+    est = res["theta"].mean(axis=0)
+    cors = [abs(np.corrcoef(est[:, h], theta[:, h])[0, 1]) for h in range(H)]
+    assert np.mean(cors) > 0.9
+    cfg = _abi.default_config(n=n, m=m, H=H, C=2, sample_iterations=200, burn_iterations=200,
+                              thin=4, seed=1, theta_os=1.0, theta_ls=H / 2)
+    cpu = oracle.run(cfg, y, theta_init=init, beta_prior_means=np.zeros((3, m)),
+                     beta_prior_sds=np.ones((3, m)))
+    est_c = cpu["theta"].mean(axis=2)
+    assert np.corrcoef(est.ravel(), est_c.ravel())[0, 1] > 0.99
+    assert res["diagnostics"]["ess_capped"] == 0
