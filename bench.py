@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Gibbs sweeps/sec of the GPIRT sampler on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one Gibbs sweep (main.m:46-87 body) over the whole synthetic response matrix of
+BASELINE.json's scale-out configuration: n = 10 000 respondents, m = 4096 items, C = 5
+ordinal categories, H = 1.  With N > 1 the items are sharded over the ranks (one process per
+GPU, `python -m torch.distributed.run ...`), the total work is fixed (strong scaling) and the
+respondent step exchanges one n-vector all-reduce per proposal round over RCCL.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (vendor data sheet; 256 CUs x 128 flop/clk x 2.4 GHz)
+HBM_PEAK_GBS = 8000.0
+
+
+def dense_flops(n, m, G):
+    """Algorithmic FP64 flop per sweep of the dense part: potrf n^3/3, nu = L Z n^2 m,
+    f* solves 2 n^2 m, K* alpha 2 G n m."""
+    return dict(potrf=n ** 3 / 3.0, nu=float(n) * n * m, fstar=2.0 * n * n * m + 2.0 * G * n * m)
+
+
+def cpu_baseline(args, n_full, m_full, G):
+    """Time the CPU oracle on a bounded sample of the same workload and scale each phase by
+    its own cost law to the full configuration."""
+    from gpirt_amd import _abi
+    from gpirt_amd.synth import generate
+    from oracle import oracle
+    n, m = args.cpu_n, args.cpu_m
+    d = generate(n, m, 5, seed=1)
+    cfg = _abi.default_config(n=n, m=m, H=1, C=5, seed=1)
+    s = oracle.Sampler(cfg, d["y"], theta_init=d["theta"])
+    s.sweep(1)                                   # warm caches / thread pool
+    p0 = s.phase_seconds()
+    t0 = time.time()
+    s.sweep(args.cpu_sweeps)
+    dt = (time.time() - t0) / args.cpu_sweeps
+    p1 = s.phase_seconds()
+    ph = {k: (p1[k] - p0[k]) / args.cpu_sweeps for k in p1}
+    rn, rm = n_full / n, m_full / m
+    scale = dict(factor=rn ** 3, nu=rn * rn * rm, ess_f=rn * rm, param=rn * rm, theta=rn * rm,
+                 snap=rn * rm,
+                 fstar=(2.0 * n_full ** 2 * m_full + 2.0 * G * n_full * m_full) /
+                       (2.0 * n ** 2 * m + 2.0 * G * n * m))
+    t_full = sum(ph[k] * scale[k] for k in ph)
+    s.close()
+    return {
+        "value": 1.0 / t_full, "unit": "sweeps/s", "cores": oracle.num_threads(), "kind": "port",
+        "sample": ("CPU restatement (oracle/gpirt_oracle.c, OpenMP), not the Rcpp package: %d timed "
+                   "sweeps at n=%d, m=%d, C=5 (%.3f s/sweep), each phase scaled by its cost law "
+                   "(potrf n^3, L*Z and solves n^2 m, likelihood passes n m) to n=%d, m=%d"
+                   % (args.cpu_sweeps, n, m, dt, n_full, m_full)),
+        "measured_sweeps_per_s_at_sample": 1.0 / dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=10000)
+    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--C", type=int, default=5)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=2500)
+    ap.add_argument("--cpu-m", type=int, default=512)
+    ap.add_argument("--cpu-sweeps", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    from gpirt_amd import _abi, _lib
+    from gpirt_amd.dist import item_range, torch_allreduce
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synth import generate
+
+    lib = _lib.lib()
+    if lib.gpirt_device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: " + "no HIP device visible")
+    _lib.check(lib.gpirt_set_device(local_rank))
+
+    dist = None
+    hook = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        hook = torch_allreduce(device_buffers=True)
+
+    n, m, C = args.n, args.m, args.C
+    data = generate(n, m, C, seed=args.seed)          # identical on every rank
+    rng = np.random.default_rng(args.seed)
+    theta_init = data["theta"] + 0.05 * rng.normal(size=data["theta"].shape)   # gpirt-sythetic.R:86
+    cfg = _abi.default_config(n=n, m=m, H=1, C=C, seed=args.seed, theta_os=1.0, theta_ls=1.0,
+                              rank=rank, world=world)
+    keep = None
+    if world > 1:
+        cfg.item_begin, cfg.item_end = item_range(m, rank, world)
+        keep = _abi.ALLREDUCE_FN(lambda ptr, count, user: hook(ptr, count))
+        cfg.allreduce = keep
+    s = Sampler(cfg, data["y"], theta_init=theta_init, beta_prior_means=np.zeros((3, m)),
+                beta_prior_sds=np.ones((3, m)))
+
+    def barrier():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    s.sweep(args.warmup)
+    ph0 = s.phase_times()
+    d0 = s.diagnostics()
+    barrier()
+    t0 = time.perf_counter()
+    s.sweep(args.steps)                  # drains its stream before returning
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ph1 = s.phase_times()
+    d1 = s.diagnostics()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        phases = {k: (ph1[k][0] - ph0[k][0]) / args.steps for k in ph1}
+        launches = {k: (ph1[k][1] - ph0[k][1]) / args.steps for k in ph1}
+        mloc = (cfg.item_end - cfg.item_begin) if world > 1 else m
+        fl = dense_flops(n, mloc, cfg.n_grid)
+        # dominant kernel: the FP64 MFMA GEMM; its single largest launch per sweep is
+        # nu = L*Z (phase "nu" is exactly that one launch, timed by HIP events on the
+        # sampler's own stream)
+        nu_ms = phases["nu"]
+        achieved = fl["nu"] / (nu_ms * 1e-3) / 1e12 if nu_ms > 0 else 0.0
+        evals = {k: (d1[k] - d0[k]) / args.steps for k in ("ess_f_rounds", "ess_param_rounds", "ess_theta_rounds")}
+        dense_ms = phases["potrf"] + phases["nu"] + phases["fstar"]
+        out = {
+            "metric": "Gibbs sweeps/sec at n=10k,m=4096,C=5",
+            "value": args.steps / elapsed,
+            "unit": "sweeps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "synthetic ordinal GPIRT, n=%d respondents, m=%d items, C=%d, H=1, "
+                                   "1001-point grid, thresholds and beta sampled" % (n, m, C),
+                       "items_per_gpu": mloc, "parallelism": "items sharded x%d" % world},
+            "roofline": {
+                "kernel": "gemm_f64_kernel<false,false> as nu = L*Z (one launch per sweep)",
+                "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                "flop_per_launch": fl["nu"], "ms_per_launch": nu_ms, "traffic": None,
+            },
+            "phases_ms": phases,
+            "launch_marks_per_step": launches,
+            "dense_tflops": (fl["potrf"] + fl["nu"] + fl["fstar"]) / (dense_ms * 1e-3) / 1e12 if dense_ms > 0 else 0.0,
+            "likelihood_evals_per_step": evals,
+            "diagnostics": d1,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, n, m, cfg.n_grid)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    s.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

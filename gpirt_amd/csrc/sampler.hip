@@ -87,7 +87,7 @@ static int host_chol_lower(std::vector<double> &A, int n) {
 
 using namespace gpirt;
 
-enum { PH_KBUILD = 0, PH_POTRF, PH_NU, PH_ESSF, PH_PARAM, PH_FSTAR, PH_THETA, PH_SNAP, PH_COUNT };
+enum { PH_KBUILD = 0, PH_POTRF, PH_NU, PH_ESSF, PH_PARAM, PH_FSTAR, PH_THETA, PH_SNAP, PH_Z, PH_COUNT };
 
 struct gpirt_sampler {
   gpirt_config cfg;
@@ -380,9 +380,10 @@ static int phase_factor(gpirt_sampler *s) {
 }
 
 static int phase_f(gpirt_sampler *s) {
-  GP_TRY(mark(s, PH_NU));
+  GP_TRY(mark(s, PH_Z));
   GP_TRY(launch_fill_normal(s->st, s->d_Z, s->Np_pad, s->Np, s->Np_pad, s->U_pad, s->mloc, s->ML,
                             s->m, s->j0, s->seed, s->sweep));
+  GP_TRY(mark(s, PH_NU));
   GemmArgs g{};  // nu = L z for every unit at once (sample_fs.m:2)
   g.A = s->d_S; g.lda = s->Np_pad; g.strideA = (int64_t)s->Np_pad * s->Np_pad;
   g.B = s->d_Z; g.ldb = s->Np_pad; g.strideB = (int64_t)s->Np_pad * s->ML;

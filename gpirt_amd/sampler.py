@@ -6,7 +6,7 @@ import numpy as np
 from . import _abi
 from ._lib import lib, check, _dp, _bp
 
-PHASES = ("k_build", "potrf", "nu", "ess_f", "ess_param", "fstar", "theta", "snap")
+PHASES = ("k_build", "potrf", "nu", "ess_f", "ess_param", "fstar", "theta", "snap", "normals")
 
 
 def _f(a):
@@ -76,8 +76,8 @@ class Sampler:
         return dict(theta=th, f=ff, fstar=fs, beta=be, threshold=tr)
 
     def phase_times(self):
-        ms = np.zeros(8)
-        cnt = np.zeros(8, dtype=np.int64)
+        ms = np.zeros(len(PHASES))
+        cnt = np.zeros(len(PHASES), dtype=np.int64)
         check(lib().gpirt_sampler_phase_times(self._h, _d(ms), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
         return {p: (float(ms[i]), int(cnt[i])) for i, p in enumerate(PHASES)}
 

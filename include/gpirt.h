@@ -182,9 +182,9 @@ int gpirt_sampler_sweep(gpirt_sampler *s, int32_t sweeps);
 int gpirt_sampler_get_state(gpirt_sampler *s, double *theta, double *f, double *fstar,
                             double *beta, double *threshold);
 /* Per-phase device time accumulated since creation (ms) and launch counts, for the
- * roofline report.  Phases: 0 k_build, 1 potrf, 2 nu=L*Z (incl. normal draws),
- * 3 ess_f, 4 ess_param, 5 fstar solves+gemm, 6 theta step, 7 snap.
- * ms[8], count[8]. */
+ * roofline report.  Phases: 0 k_build, 1 potrf, 2 nu=L*Z (one GEMM launch per sweep),
+ * 3 ess_f, 4 ess_param, 5 fstar solves+gemm, 6 theta step, 7 snap, 8 normal draws.
+ * ms[9], count[9]. */
 int gpirt_sampler_phase_times(gpirt_sampler *s, double *ms, int64_t *count);
 /* Diagnostics so far: fills the counters of `out` (buffers untouched). */
 int gpirt_sampler_diagnostics(gpirt_sampler *s, gpirt_outputs *out);

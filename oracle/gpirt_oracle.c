@@ -30,6 +30,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -343,6 +344,7 @@ typedef struct orc_sampler {
   int64_t r_f, r_p, r_t, capped;
   int jitter_retries;
   double last_ll;
+  double phase_s[7]; /* factor, nu, ess_f, param, fstar, theta, snap */
 } orc_sampler;
 
 static void params_from_white(const orc_sampler *s, int u, const double *e, const double *dl,
@@ -492,17 +494,35 @@ static void unit_mu(const orc_sampler *s, int u, const double *beta, double *mu)
   for (int r = 0; r < s->Np; ++r) mu[r] = beta[0] + beta[1] * x[r] + beta[2] * x[r] * x[r];
 }
 
+static double now_s(void) {
+#ifdef _OPENMP
+  return omp_get_wtime();
+#else
+  return (double)clock() / CLOCKS_PER_SEC;
+#endif
+}
+
 static void phase_f(orc_sampler *s) {
   int Np = s->Np, U = s->U, C = s->C, R = s->cfg.max_ess_rounds;
   int64_t rounds_tot = 0, capped = 0;
+  double t0 = now_s();
+  double *NU = (double *)malloc(sizeof(double) * (size_t)Np * U);
+#pragma omp parallel for schedule(dynamic)
+  for (int u = 0; u < U; ++u) {   /* nu_u = L z_u  (sample_fs.m:2) */
+    uint32_t ug = global_unit(s, u);
+    double *z = (double *)malloc(sizeof(double) * (size_t)Np);
+    for (int r = 0; r < Np; ++r) z[r] = rng_normal_at(s->seed, TAG_F_Z, s->sweep, ug, (uint32_t)r);
+    orc_trmm_lz(s->L + (size_t)Np * Np * (u / s->mloc), z, Np, 1, NU + (size_t)Np * u);
+    free(z);
+  }
+  double t1 = now_s();
+  s->phase_s[1] += t1 - t0;
 #pragma omp parallel for schedule(dynamic) reduction(+ : rounds_tot, capped)
   for (int u = 0; u < U; ++u) {
     uint32_t ug = global_unit(s, u);
-    double *z = (double *)malloc(sizeof(double) * (size_t)Np * 3);
-    double *nu = z + Np, *mu = z + 2 * (size_t)Np;
+    double *mu = (double *)malloc(sizeof(double) * (size_t)Np);
+    double *nu = NU + (size_t)Np * u;
     double *un = (double *)malloc(sizeof(double) * (size_t)(R + 2));
-    for (int r = 0; r < Np; ++r) z[r] = rng_normal_at(s->seed, TAG_F_Z, s->sweep, ug, (uint32_t)r);
-    orc_trmm_lz(s->L + (size_t)Np * Np * (u / s->mloc), z, Np, 1, nu);  /* sample_fs.m:2 */
     unit_mu(s, u, s->beta + 3 * (size_t)u, mu);
     for (int d = 0; d < R + 2; ++d) un[d] = rng_uniform_at(s->seed, TAG_F_U, s->sweep, ug, (uint32_t)d);
     int32_t rr;
@@ -510,8 +530,10 @@ static void phase_f(orc_sampler *s) {
               s->bthr + (size_t)(C + 1) * u, un, Np, 1, C, R, &rr, NULL);
     rounds_tot += 1 + (rr < 0 ? -rr : rr);
     if (rr < 0) capped++;
-    free(z); free(un);
+    free(mu); free(un);
   }
+  free(NU);
+  s->phase_s[2] += now_s() - t1;
   s->r_f += rounds_tot; s->capped += capped;
 }
 
@@ -752,13 +774,20 @@ static double total_loglik(const orc_sampler *s) {
 ORC_API int orc_sampler_sweep(orc_sampler *s, int32_t sweeps) {
   for (int it = 0; it < sweeps; ++it) {
     int rc;
+    double t = now_s(), t2;
     if ((rc = phase_factor(s))) return rc;     /* main.m:67 (+ chol of sample_fs.m:2) */
+    t2 = now_s(); s->phase_s[0] += t2 - t; t = t2;
     phase_f(s);                                 /* main.m:50-52 */
+    t = now_s();
     phase_param(s);
+    t2 = now_s(); s->phase_s[3] += t2 - t; t = t2;
     phase_fstar(s);                             /* main.m:55-60 */
+    t2 = now_s(); s->phase_s[4] += t2 - t; t = t2;
     rc = s->cfg.theta_mode == GPIRT_THETA_GRID ? phase_theta_grid(s) : phase_theta_ess(s); /* :63 */
     if (rc) return rc;
+    t2 = now_s(); s->phase_s[5] += t2 - t; t = t2;
     phase_snap(s);                              /* main.m:69-73 */
+    s->phase_s[6] += now_s() - t;
     s->sweep++;
   }
   return 0;
@@ -794,6 +823,10 @@ ORC_API int orc_sampler_diagnostics(orc_sampler *s, gpirt_outputs *o) {
 }
 
 ORC_API double orc_sampler_loglik(orc_sampler *s) { return total_loglik(s); }
+
+ORC_API void orc_sampler_phase_seconds(orc_sampler *s, double *out) {
+  memcpy(out, s->phase_s, sizeof s->phase_s);
+}
 
 ORC_API int orc_run(const gpirt_config *cfg, const int8_t *y, const double *theta_init,
                     const double *bpm, const double *bps, const double *tpm, const double *tps,

@@ -207,6 +207,11 @@ class Sampler:
     def loglik(self):
         return lib().orc_sampler_loglik(self._h)
 
+    def phase_seconds(self):
+        out = np.zeros(7)
+        lib().orc_sampler_phase_seconds(self._h, _d(out))
+        return dict(zip(("factor", "nu", "ess_f", "param", "fstar", "theta", "snap"), out.tolist()))
+
     def diagnostics(self):
         o = _abi.GpirtOutputs()
         lib().orc_sampler_diagnostics(self._h, C.byref(o))
