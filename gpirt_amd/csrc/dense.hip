@@ -22,62 +22,67 @@ constexpr int LDS_LD = 144;   // 128 + 16: the four k-rows one ds_read_b64 touch
 // register hold 16 consecutive rows i of one column j: the epilogue then writes 128-byte
 // runs of the column-major C instead of 8-byte scatters.
 // ---------------------------------------------------------------------------------------
+// Global -> register staging of one 128 x BK operand slab (4 x 16 B per thread) and its
+// store into the k-major LDS image.  KCONTIG says which index is contiguous in memory.
+// The four registers are separate scalars on purpose: as an array they ended up in scratch.
 template <bool KCONTIG>
-__device__ inline void tile_load(const double *__restrict__ base, int64_t ld, int row0, int k0,
-                                 int tid, double2 (&r)[4]) {
-  if (!KCONTIG) {  // element (row,k) at base[row + ld*k]: rows contiguous
-    int kl = tid >> 6, r2 = (tid & 63) * 2;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      r[p] = *reinterpret_cast<const double2 *>(base + (row0 + r2) + ld * (int64_t)(k0 + kl + 4 * p));
-  } else {         // element (row,k) at base[k + ld*row]: k contiguous
-    int rl = tid >> 3, k2 = (tid & 7) * 2;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      r[p] = *reinterpret_cast<const double2 *>(base + (k0 + k2) + ld * (int64_t)(row0 + rl + 32 * p));
-  }
+__device__ __forceinline__ double2 slab_ld(const double *__restrict__ base, int64_t ld, int row0,
+                                           int k0, int tid, int p) {
+  if (!KCONTIG)
+    return *reinterpret_cast<const double2 *>(base + (row0 + ((tid & 63) << 1)) +
+                                              ld * (int64_t)(k0 + (tid >> 6) + 4 * p));
+  return *reinterpret_cast<const double2 *>(base + (k0 + ((tid & 7) << 1)) +
+                                            ld * (int64_t)(row0 + (tid >> 3) + 32 * p));
 }
 
 template <bool KCONTIG>
-__device__ inline void tile_store(double (*s)[LDS_LD], int tid, const double2 (&r)[4]) {
+__device__ __forceinline__ void slab_st(double (*s)[LDS_LD], int tid, int p, double2 v) {
   if (!KCONTIG) {
-    int kl = tid >> 6, r2 = (tid & 63) * 2;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<double2 *>(&s[kl + 4 * p][r2]) = r[p];
+    *reinterpret_cast<double2 *>(&s[(tid >> 6) + 4 * p][(tid & 63) << 1]) = v;
   } else {
-    int rl = tid >> 3, k2 = (tid & 7) * 2;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      s[k2][rl + 32 * p] = r[p].x;
-      s[k2 + 1][rl + 32 * p] = r[p].y;
-    }
+    s[(tid & 7) << 1][(tid >> 3) + 32 * p] = v.x;
+    s[((tid & 7) << 1) + 1][(tid >> 3) + 32 * p] = v.y;
   }
 }
 
-template <bool AT, bool BT>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g, int nbm, int nbn) {
+#define TILE_LOAD(KC, base, ld, row0, k0, r)          \
+  r##0 = slab_ld<KC>(base, ld, row0, k0, tid, 0);     \
+  r##1 = slab_ld<KC>(base, ld, row0, k0, tid, 1);     \
+  r##2 = slab_ld<KC>(base, ld, row0, k0, tid, 2);     \
+  r##3 = slab_ld<KC>(base, ld, row0, k0, tid, 3)
+#define TILE_STORE(KC, s, r)   \
+  slab_st<KC>(s, tid, 0, r##0); \
+  slab_st<KC>(s, tid, 1, r##1); \
+  slab_st<KC>(s, tid, 2, r##2); \
+  slab_st<KC>(s, tid, 3, r##3)
+
+// MODE: 0 plain, 1 lower tiles only (C square), 2 A lower-triangular (K range of row-block
+// bi is [0,(bi+1)*TILE)), 3 A^T with A lower-triangular (K range [bi*TILE, K)).
+template <bool AT, bool BT, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, int nbn) {
   __shared__ double sA[2][BK][LDS_LD];
   __shared__ double sB[2][BK][LDS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int t = blockIdx.x, bi, bj;
-  if (g.lower_only) {
+  if (MODE == 1) {
     bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
     while ((int64_t)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
     while ((int64_t)bi * (bi + 1) / 2 > t) --bi;
     bj = t - (int)((int64_t)bi * (bi + 1) / 2);
-  } else if (g.k_trim == 1) {   // longest K first
+  } else if (MODE == 2) {   // longest K first
     bi = nbm - 1 - t / nbn; bj = t % nbn;
   } else {
     bi = t / nbn; bj = t % nbn;
   }
   const int z = blockIdx.y;
-  const double *A = g.A + g.strideA * z;
-  const double *B = g.B + g.strideB * z;
-  double *C = g.C + g.strideC * z;
+  const double *__restrict__ A = g.A + g.strideA * z;
+  const double *__restrict__ B = g.B + g.strideB * z;
+  double *__restrict__ C = g.C + g.strideC * z;
   const int i0 = bi * TILE, j0 = bj * TILE;
   int kbeg = 0, kend = g.K;
-  if (g.k_trim == 1) kend = min(g.K, (bi + 1) * TILE);
-  if (g.k_trim == 2) kbeg = bi * TILE;
+  if (MODE == 2) kend = min(g.K, (bi + 1) * TILE);
+  if (MODE == 3) kbeg = bi * TILE;
+  const int64_t lda = g.lda, ldb = g.ldb;
 
   v4d acc[4][4];
 #pragma unroll
@@ -85,45 +90,57 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g, int nbm, int 
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-  double2 ra[4], rb[4];
-  tile_load<AT>(A, g.lda, i0, kbeg, tid, ra);
-  tile_load<!BT>(B, g.ldb, j0, kbeg, tid, rb);
-  tile_store<AT>(sA[0], tid, ra);
-  tile_store<!BT>(sB[0], tid, rb);
+  double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  TILE_LOAD(AT, A, lda, i0, kbeg, ra);
+  TILE_LOAD(!BT, B, ldb, j0, kbeg, rb);
+  TILE_STORE(AT, sA[0], ra);
+  TILE_STORE(!BT, sB[0], rb);
   __syncthreads();
 
   const int wm0 = (wave & 1) * 64, wn0 = (wave >> 1) * 64;
   const int lr = lane & 15, lk = lane >> 4;
+  const int klast = kend - BK;
   int buf = 0;
+  // single-block loop body: the prefetch of the slab after the last one re-reads the last
+  // slab (clamped index) and its LDS store lands in the idle buffer
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
-    if (more) {
-      tile_load<AT>(A, g.lda, i0, k0 + BK, tid, ra);
-      tile_load<!BT>(B, g.ldb, j0, k0 + BK, tid, rb);
+    const int kn = min(k0 + BK, klast);
+    TILE_LOAD(AT, A, lda, i0, kn, ra);
+    TILE_LOAD(!BT, B, ldb, j0, kn, rb);
+    // fragments of k-step kk+1 are read while the 16 MFMAs of k-step kk issue
+    double fa[2][4], fb[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      fa[0][q] = sB[buf][lk][wn0 + q * 16 + lr];  // MFMA row index  = j
+      fb[0][q] = sA[buf][lk][wm0 + q * 16 + lr];  // MFMA col index  = i
     }
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      double fa[4], fb[4];
+      if (kk + 1 < BK / 4) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        fa[q] = sB[buf][kk * 4 + lk][wn0 + q * 16 + lr];  // MFMA row index  = j
-        fb[q] = sA[buf][kk * 4 + lk][wm0 + q * 16 + lr];  // MFMA col index  = i
+        for (int q = 0; q < 4; ++q) {
+          fa[(kk + 1) & 1][q] = sB[buf][(kk + 1) * 4 + lk][wn0 + q * 16 + lr];
+          fb[(kk + 1) & 1][q] = sA[buf][(kk + 1) * 4 + lk][wm0 + q * 16 + lr];
+        }
       }
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
-          acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[tj], fb[ti], acc[tj][ti], 0, 0, 0);
+          acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk & 1][tj], fb[kk & 1][ti],
+                                                             acc[tj][ti], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) {
-      tile_store<AT>(sA[buf ^ 1], tid, ra);
-      tile_store<!BT>(sB[buf ^ 1], tid, rb);
-    }
+    // the sched barriers keep the staging stores (and the wait for the global loads they
+    // need) behind the MFMAs of this slab: the loads' latency is covered by the matrix work
+    TILE_STORE(AT, sA[buf ^ 1], ra);
+    TILE_STORE(!BT, sB[buf ^ 1], rb);
     __syncthreads();
     buf ^= 1;
   }
 
   const double alpha = g.alpha, beta = g.beta;
+  const int64_t ldc = g.ldc;
 #pragma unroll
   for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
@@ -132,11 +149,24 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g, int nbm, int 
       for (int r = 0; r < 4; ++r) {
         int j = j0 + wn0 + tj * 16 + lk + 4 * r;
         int i = i0 + wm0 + ti * 16 + lr;
-        double *c = C + i + g.ldc * (int64_t)j;
+        double *c = C + i + ldc * (int64_t)j;
         double v = alpha * acc[tj][ti][r];
         if (beta != 0.0) v += beta * *c;
         *c = v;
       }
+}
+
+template <bool AT, bool BT>
+static int launch_gemm_mode(hipStream_t st, const GemmArgs &a, int mode, dim3 grid, int nbm, int nbn) {
+  dim3 block(256);
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, 0>), grid, block, 0, st, a, nbm, nbn); break;
+    case 1: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, 1>), grid, block, 0, st, a, nbm, nbn); break;
+    case 2: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, 2>), grid, block, 0, st, a, nbm, nbn); break;
+    default: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, 3>), grid, block, 0, st, a, nbm, nbn); break;
+  }
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
 }
 
 int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
@@ -146,14 +176,15 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
     return GPIRT_ERR_BAD_ARG;
   }
   int nbm = a.M / TILE, nbn = a.N / TILE;
+  int mode = a.lower_only ? 1 : (a.k_trim == 1 ? 2 : (a.k_trim == 2 ? 3 : 0));
   int64_t tiles = a.lower_only ? (int64_t)nbm * (nbm + 1) / 2 : (int64_t)nbm * nbn;
-  dim3 grid((unsigned)tiles, (unsigned)a.batch), block(256);
-  if (!AT && !BT) hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, st, a, nbm, nbn);
-  else if (!AT && BT) hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, 0, st, a, nbm, nbn);
-  else if (AT && !BT) hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, 0, st, a, nbm, nbn);
-  else hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, 0, st, a, nbm, nbn);
-  GP_HIP(hipGetLastError());
-  return GPIRT_OK;
+  dim3 grid((unsigned)tiles, (unsigned)a.batch);
+  // only the combinations the sweep uses are instantiated
+  if (!AT && !BT && (mode == 0 || mode == 2)) return launch_gemm_mode<false, false>(st, a, mode, grid, nbm, nbn);
+  if (!AT && BT && (mode == 0 || mode == 1)) return launch_gemm_mode<false, true>(st, a, mode, grid, nbm, nbn);
+  if (AT && !BT && mode == 0) return launch_gemm_mode<true, false>(st, a, mode, grid, nbm, nbn);
+  set_error("launch_gemm: combination AT=%d BT=%d mode=%d is not built", (int)AT, (int)BT, mode);
+  return GPIRT_ERR_BAD_ARG;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -211,71 +242,15 @@ int launch_kstar_t(hipStream_t st, const double *x, int64_t x_stride, int n, int
   return GPIRT_OK;
 }
 
-// ---------------------------------------------------------------------------------------
-// Diagonal-block factorisation: one workgroup factors a 128x128 block held in LDS and
-// inverts the factor.  The inverse (lower triangular) is built transposed in the strict
-// upper triangle of the same LDS image, so one 132 KB array holds both.
-// ---------------------------------------------------------------------------------------
-constexpr int DLD = TILE + 1;
-
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S, int n_pad, int kb,
-                                                        double *__restrict__ inv_diag, int nb,
-                                                        int *__restrict__ info) {
-  __shared__ double T[TILE][DLD];
-  __shared__ double col[TILE];
-  __shared__ double xd[TILE];
-  const int z = blockIdx.x, tid = threadIdx.x;
-  double *A = S + (int64_t)n_pad * n_pad * z + (int64_t)kb * TILE * (n_pad + 1);
-  double *Inv = inv_diag + (int64_t)TILE * TILE * (kb + (int64_t)nb * z);
-
-  for (int e = tid; e < TILE * TILE; e += 256) {
-    int i = e & (TILE - 1), j = e >> 7;
-    T[i][j] = (i >= j) ? A[i + (int64_t)n_pad * j] : 0.0;
-  }
-  __syncthreads();
-
-  const int row = tid & (TILE - 1), half = tid >> 7;
-  for (int j = 0; j < TILE; ++j) {
-    double d = T[j][j];
-    if (!(d > 0.0)) {
-      if (tid == 0) atomicMax(info, kb * TILE + j + 1);
-      d = 1.0;
-    }
-    double rs = 1.0 / sqrt(d);
-    if (half == 0 && row >= j) col[row] = T[row][j] * rs;
-    __syncthreads();
-    if (half == 0 && row >= j) T[row][j] = col[row];
-    const double ci = col[row];
-    for (int c = j + 1 + half; c <= row; c += 2) T[row][c] -= ci * col[c];
-    __syncthreads();
-  }
-
-  // inverse of the factor, column t by thread t, stored transposed: X[i][t] -> T[t][i] (i>t)
-  if (tid < TILE) {
-    const int t = tid;
-    xd[t] = 1.0 / T[t][t];
-    for (int i = t + 1; i < TILE; ++i) {
-      double s = T[i][t] * xd[t];
-      for (int c = t + 1; c < i; ++c) s += T[i][c] * T[t][c];
-      T[t][i] = -s / T[i][i];
-    }
-  }
-  __syncthreads();
-
-  for (int e = tid; e < TILE * TILE; e += 256) {
-    int i = e & (TILE - 1), j = e >> 7;
-    A[i + (int64_t)n_pad * j] = (i >= j) ? T[i][j] : 0.0;
-    Inv[i + TILE * j] = (i > j) ? T[j][i] : (i == j ? xd[i] : 0.0);
-  }
-}
+// defined in potrf_diag.hip
+int launch_potrf_diag(hipStream_t st, double *S, int n_pad, int kb, int batch, double *inv_diag, int nb,
+                      int *d_info);
 
 int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv_diag, int *d_info) {
   const int nb = n_pad / TILE;
   const int64_t sS = (int64_t)n_pad * n_pad, sI = (int64_t)TILE * TILE * nb;
   for (int k = 0; k < nb; ++k) {
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, st, S, n_pad, k, inv_diag, nb,
-                       d_info);
-    GP_HIP(hipGetLastError());
+    GP_TRY(launch_potrf_diag(st, S, n_pad, k, batch, inv_diag, nb, d_info));
     int rem = nb - 1 - k;
     if (!rem) break;
     double *panel = S + (int64_t)(k + 1) * TILE + (int64_t)n_pad * k * TILE;
