@@ -23,15 +23,23 @@ class _DevVec:
             "strides": None}
 
 
-def torch_allreduce(group=None, device_buffers=True):
+def torch_allreduce(group=None, device_buffers=True, via_host=False):
     """Return ``f(ptr, count) -> 0`` summing `count` doubles at `ptr` over the process group,
     in place.  `device_buffers=True`: `ptr` is HBM on the current device (HIP backend);
-    False: `ptr` is host memory (CPU rehearsal with gloo)."""
+    False: `ptr` is host memory (CPU rehearsal with gloo).  `via_host=True` stages a device
+    buffer through host memory so that a gloo group can carry it (several ranks sharing one
+    GPU in a test; RCCL refuses two ranks on one device)."""
     import torch
     import torch.distributed as dist
 
     def hook(ptr, count):
-        if device_buffers:
+        if device_buffers and via_host:
+            t = torch.as_tensor(_DevVec(ptr, count), device="cuda")
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+            torch.cuda.current_stream().synchronize()
+        elif device_buffers:
             t = torch.as_tensor(_DevVec(ptr, count), device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             torch.cuda.current_stream().synchronize()

@@ -1,0 +1,98 @@
+"""The item-sharded DEVICE path: two ranks share the one GPU of the test box (a gloo group
+carries the exchange through host memory, because RCCL refuses two ranks on one device), and a
+one-rank RCCL group checks the hook the 8-GPU benchmark uses."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from gpirt_amd import _abi
+    from gpirt_amd.dist import item_range, torch_allreduce
+    from gpirt_amd.sampler import Sampler
+    from conftest import load_fixture
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = load_fixture("Wiener_C_5")
+    y, theta = d["y"][:, :, :3], d["theta"][:, :3]
+    n, m, H = y.shape
+    j0, j1 = item_range(m, rank, world)
+    hook = torch_allreduce(device_buffers=True, via_host=True)
+    cb = _abi.ALLREDUCE_FN(lambda ptr, count, user: hook(ptr, count))
+    cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=11, theta_ls=1.5, item_begin=j0, item_end=j1,
+                              rank=rank, world=world)
+    cfg.allreduce = cb
+    s = Sampler(cfg, y, theta_init=theta)
+    s.sweep(3)
+    st = s.state()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), j0=j0, j1=j1, **st)
+    s.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_unsharded_device_chain(tmp_path):
+    import torch.multiprocessing as mp
+    from gpirt_amd import _abi
+    from gpirt_amd.sampler import Sampler
+    from conftest import load_fixture
+
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    d = load_fixture("Wiener_C_5")
+    y, theta = d["y"][:, :, :3], d["theta"][:, :3]
+    n, m, H = y.shape
+    cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=11, theta_ls=1.5)
+    ref = Sampler(cfg, y, theta_init=theta)
+    ref.sweep(3)
+    full = ref.state()
+    ref.close()
+    for r in range(2):
+        p = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        j0, j1 = int(p["j0"]), int(p["j1"])
+        assert np.abs(p["theta"] - full["theta"]).max() < 1e-9
+        assert np.abs(p["f"] - full["f"][:, j0:j1]).max() < 1e-6
+        assert np.abs(p["fstar"] - full["fstar"][:, j0:j1]).max() < 1e-6
+        assert np.abs(p["beta"] - full["beta"][:, j0:j1]).max() < 1e-9
+
+
+def _nccl_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from gpirt_amd.dist import torch_allreduce
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    x = torch.arange(1000, dtype=torch.float64, device="cuda")
+    hook = torch_allreduce(device_buffers=True)
+    assert hook(x.data_ptr(), x.numel()) == 0        # raw device pointer, as the library passes it
+    ok = bool(torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float64)))
+    open(out, "w").write("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+def test_rccl_hook_on_a_raw_device_pointer(tmp_path):
+    import torch.multiprocessing as mp
+    out = os.path.join(str(tmp_path), "r.txt")
+    mp.spawn(_nccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert open(out).read() == "ok"
