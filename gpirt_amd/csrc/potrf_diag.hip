@@ -1,32 +1,98 @@
 // Diagonal-block kernel of the blocked Cholesky (chol inside mvnrnd, utils/sample_fs.m:2):
-// factor one 128x128 block and invert the factor.  Kept in its own file because the fully
-// unrolled code takes long to compile.
+// factor one 128x128 block and invert the factor.
 #include "common.h"
 
 namespace gpirt {
 
-// ---------------------------------------------------------------------------------------
-// Diagonal-block factorisation: one workgroup factors a 128x128 block and inverts the
-// factor.  The block lives in registers: thread (r, h) = (tid/2, tid%2) owns the 64 entries
-// of row r in the column pairs {4q+2h, 4q+2h+1}, q = 0..31, so both threads of a row carry
-// the same load at every step and read the pivot column from LDS as 16-byte pairs.  The
-// 128 pivot steps are fully unrolled (static register indices); each costs one barrier.
-// The inverse X = L^-1 is then built row by row with no barrier at all: thread (t, h) owns
-// the same column pairs of column t of X and the two halves meet in one lane shuffle.
-// ---------------------------------------------------------------------------------------
-constexpr int XLD = TILE + 2;   // row stride of the LDS image: column pairs stay 16-byte aligned
+typedef double v4d __attribute__((ext_vector_type(4)));
 
-// The block stays in LDS (row-major, stride XLD).  Thread (r, h) = (tid/2, tid%2) owns, in row
-// r, the column pairs 2p, 2p+1 with p % 2 == h.  A pivot step costs ONE barrier: right after
-// updating its pairs a thread copies its (already final, still unscaled) entry of the next
-// pivot column into a double-buffered column vector; after the barrier every thread reads the
-// pivot d and that vector and applies T[r][c] -= (u_r / d) * u_c on the lower triangle.
+constexpr int XLD = TILE + 2;   // row stride of the LDS image (even: pairs stay 16-byte aligned)
+constexpr int SB = 32;          // inner block size
+constexpr int MLD = 18;         // row stride of the per-wave 32x16 scratch
+
+__device__ __forceinline__ v4d mfma4(double a, double b, v4d c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// 1/sqrt(d): hardware estimate plus two Newton steps
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * (1.5 - 0.5 * d * y * y);
+  y = y * (1.5 - 0.5 * d * y * y);
+  return y;
+}
+
+// The inverse X = L^-1 is kept transposed in the strict upper triangle of the same LDS image
+// (X[r][c], r > c, at T[c][r]) with its diagonal in dinv: one 133 KB image holds L and X.
+__device__ __forceinline__ double x_at(const double *T, const double *dinv, int r, int c) {
+  return r > c ? T[c * XLD + r] : (r == c ? dinv[r] : 0.0);
+}
+
+// ---- inner 32x32 block on one wave (lanes 0..31): row r of the block in registers ----------
+template <int J>
+__device__ __forceinline__ void blk_factor_step(double (&a)[SB], double *ucol, double *dinv_p, int r,
+                                                int &bad) {
+  ucol[r] = a[J];                         // wave-local exchange: LDS ops of a wave stay in order
+  double d = ucol[J];
+  if (!(d > 0.0)) { bad = J + 1; d = 1.0; }
+  const double y = rsqrt_nr(d);
+  const double w = a[J] * (y * y);        // A[r][J] / d
+  a[J] = a[J] * y;                        // L[r][J]
+  if (r == J) dinv_p[J] = y;
+#pragma unroll
+  for (int c = J + 1; c < SB; ++c) {
+    a[c] -= w * ucol[c];
+    // pin the update to this step: left alone, the compiler defers every update that the
+    // next pivot does not need and keeps w and the pivot column of all 32 steps alive
+    asm volatile("" : "+v"(a[c]));
+  }
+}
+template <int J0, int J1>
+__device__ __forceinline__ void blk_factor_range(double (&a)[SB], double *ucol, double *dinv_p, int r,
+                                                 int &bad) {
+  if constexpr (J0 < J1) {
+    blk_factor_step<J0>(a, ucol, dinv_p, r, bad);
+    blk_factor_range<J0 + 1, J1>(a, ucol, dinv_p, r, bad);
+  }
+}
+
+// column t of the inverse of the 32x32 factor; Tp points at the block's (0,0) entry
+template <int I>
+__device__ __forceinline__ void blk_inverse_step(double (&x)[SB], const double *Tp, const double *dinv_p,
+                                                 int t) {
+  const double *Lr = Tp + I * XLD;
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int c = 0; c + 1 < I; c += 2) {
+    s0 += Lr[c] * x[c];
+    s1 += Lr[c + 1] * x[c + 1];
+  }
+  if (I & 1) s0 += Lr[I - 1] * x[I - 1];
+  x[I] = ((I == t ? 1.0 : 0.0) - (s0 + s1)) * dinv_p[I];
+  asm volatile("" : "+v"(x[I]));
+}
+template <int I0, int I1>
+__device__ __forceinline__ void blk_inverse_range(double (&x)[SB], const double *Tp,
+                                                  const double *dinv_p, int t) {
+  if constexpr (I0 < I1) {
+    blk_inverse_step<I0>(x, Tp, dinv_p, t);
+    blk_inverse_range<I0 + 1, I1>(x, Tp, dinv_p, t);
+  }
+}
+
+// One workgroup (4 waves) factors a 128x128 block in LDS and inverts the factor, blocked by
+// 32: wave 0 factors and inverts the 32x32 diagonal block in registers, then all four waves
+// apply the panel solve and the trailing update with FP64 MFMA straight from LDS.  The
+// off-diagonal blocks of the inverse follow by block substitution, again on MFMA.
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S, int n_pad, int kb,
                                                         double *__restrict__ inv_diag, int nb,
                                                         int *__restrict__ info) {
   __shared__ __attribute__((aligned(16))) double T[TILE * XLD];
-  __shared__ __attribute__((aligned(16))) double colb[2][TILE];
-  const int z = blockIdx.x, tid = threadIdx.x, r = tid >> 1, h = tid & 1;
+  __shared__ __attribute__((aligned(16))) double dinv[TILE];
+  __shared__ __attribute__((aligned(16))) double ucol[SB];
+  __shared__ __attribute__((aligned(16))) double Ms[4][SB * MLD];
+  const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
   double *A = S + (int64_t)n_pad * n_pad * z + (int64_t)kb * TILE * (n_pad + 1);
   double *Inv = inv_diag + (int64_t)TILE * TILE * (kb + (int64_t)nb * z);
 
@@ -35,85 +101,122 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
     T[i * XLD + c] = (i >= c) ? A[i + (int64_t)n_pad * c] : 0.0;
   }
   __syncthreads();
-  double *Tr = &T[r * XLD];
-  if (h == 0) colb[0][r] = Tr[0];
-  __syncthreads();
 
-  for (int j = 0; j < TILE; ++j) {
-    const double *cb = colb[j & 1];
-    double d = cb[j];
-    if (!(d > 0.0)) {
-      if (tid == 0) atomicMax(info, kb * TILE + j + 1);
-      d = 1.0;
+  for (int p = 0; p < TILE / SB; ++p) {
+    const int i0 = p * SB;
+    double *Tp = &T[i0 * XLD + i0];
+    if (wave == 0 && lane < SB) {
+      const int r = lane;
+      double a[SB];
+#pragma unroll
+      for (int c = 0; c < SB; ++c) a[c] = Tp[r * XLD + c];
+      int bad = 0;
+      blk_factor_range<0, SB>(a, ucol, &dinv[i0], r, bad);
+      if (bad && r == 0) atomicMax(info, kb * TILE + i0 + bad);
+#pragma unroll
+      for (int c = 0; c < SB; ++c) Tp[r * XLD + c] = c <= r ? a[c] : 0.0;
+      // inverse of the diagonal block: lane t owns column t
+      double x[SB];
+#pragma unroll
+      for (int c = 0; c < SB; ++c) x[c] = 0.0;
+      blk_inverse_range<0, SB>(x, Tp, &dinv[i0], r);
+#pragma unroll
+      for (int i = 1; i < SB; ++i)
+        if (i > r) Tp[r * XLD + i] = x[i];        // X[i][t] at T[t][i]
     }
-    const double rs = 1.0 / sqrt(d);
-    const double ur = cb[r];
-    const double w = ur * (rs * rs);
-    const int pj = j >> 1;                  // pair holding the pivot column
-    if (r >= j && (pj & 1) == h) {
-      Tr[j] = ur * rs;                      // L[r][j]
-      if (!(j & 1) && r > j) Tr[j + 1] -= w * cb[j + 1];
-    }
-    if (r > j) {
-      // first pair strictly right of the pivot pair that this thread owns, up to the diagonal
-      int p = pj + 1;
-      if ((p & 1) != h) ++p;
-      const int pend = r >> 1;
-      for (; p <= pend; p += 2) {
-        const double2 cc = *reinterpret_cast<const double2 *>(&cb[2 * p]);
-        double2 v = *reinterpret_cast<double2 *>(&Tr[2 * p]);
-        v.x -= w * cc.x;
-        v.y -= w * cc.y;
-        *reinterpret_cast<double2 *>(&Tr[2 * p]) = v;
+    __syncthreads();
+
+    const int R = TILE - i0 - SB;                  // rows below the diagonal block
+    const int NT = R / 16;
+    // panel: L_ip = A_ip * X_pp^T, a wave owns whole 16-row strips (reads before its writes)
+    for (int rb = wave; rb < NT; rb += 4) {
+      const int ib = i0 + SB + 16 * rb;
+      v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < SB / 4; ++kk) {
+        const int k = 4 * kk + lk;
+        const double av = T[(ib + lr) * XLD + i0 + k];
+        const double b0 = x_at(T, dinv, i0 + lr, i0 + k);
+        const double b1 = x_at(T, dinv, i0 + 16 + lr, i0 + k);
+        acc0 = mfma4(av, b0, acc0);
+        acc1 = mfma4(av, b1, acc1);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        T[(ib + lk + 4 * g) * XLD + i0 + lr] = acc0[g];
+        T[(ib + lk + 4 * g) * XLD + i0 + 16 + lr] = acc1[g];
       }
     }
-    // publish this row's entry of the next pivot column (final after the update above)
-    if (j + 1 < TILE && (((j + 1) >> 1) & 1) == h) colb[(j + 1) & 1][r] = Tr[j + 1];
+    __syncthreads();
+    // trailing update on the lower 16x16 tiles: A_ij -= L_ip L_jp^T
+    for (int e = wave; e < NT * (NT + 1) / 2; e += 4) {
+      int ti = 0;
+      while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
+      const int tj = e - ti * (ti + 1) / 2;
+      const int ri = i0 + SB + 16 * ti, rj = i0 + SB + 16 * tj;
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < SB / 4; ++kk) {
+        const int k = i0 + 4 * kk + lk;
+        acc = mfma4(T[(ri + lr) * XLD + k], T[(rj + lr) * XLD + k], acc);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) T[(ri + lk + 4 * g) * XLD + rj + lr] -= acc[g];
+    }
     __syncthreads();
   }
 
-  // clear what the update loop wrote above the diagonal (entry (r, r+1) for even r), then
-  // L back to global
-  if (h == 0 && !(r & 1)) Tr[r + 1] = 0.0;
-  __syncthreads();
+  // the diagonal tiles of the trailing update also wrote their upper halves: L's strict upper
+  // triangle inside each 32-block was re-zeroed by the factor step, the rest of the upper
+  // triangle is where X goes next.  L back to global first.
   for (int e = tid; e < TILE * TILE; e += 256) {
     const int i = e & (TILE - 1), c = e >> 7;
-    A[i + (int64_t)n_pad * c] = T[i * XLD + c];
+    A[i + (int64_t)n_pad * c] = (i >= c) ? T[i * XLD + c] : 0.0;
+  }
+  __syncthreads();
+
+  // off-diagonal blocks of X = L^-1 by block substitution, one distance level at a time:
+  //   X_ip = -X_ii * sum_{k=p}^{i-1} L_ik X_kp
+  // A task is a 32x16 column strip of X_ip: the inner sum goes to the wave's scratch, the
+  // product with X_ii reads it back as the MFMA's second operand.
+  double *M = Ms[wave];
+  for (int dlev = 1; dlev < TILE / SB; ++dlev) {
+    const int ntask = 2 * (TILE / SB - dlev);
+    for (int task = wave; task < ntask; task += 4) {
+      const int p = task >> 1, cs = task & 1, i = p + dlev;
+      const int i0 = p * SB, i1 = i * SB, c0 = i0 + 16 * cs;
+      v4d m0 = {0.0, 0.0, 0.0, 0.0}, m1 = {0.0, 0.0, 0.0, 0.0};
+      for (int kk = 0; kk < (SB / 4) * dlev; ++kk) {
+        const int k = i0 + 4 * kk + lk;                      // global column of L / row of X
+        const double bv = x_at(T, dinv, k, c0 + lr);
+        m0 = mfma4(T[(i1 + lr) * XLD + k], bv, m0);
+        m1 = mfma4(T[(i1 + 16 + lr) * XLD + k], bv, m1);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        M[(lk + 4 * g) * MLD + lr] = m0[g];
+        M[(16 + lk + 4 * g) * MLD + lr] = m1[g];
+      }
+      v4d o0 = {0.0, 0.0, 0.0, 0.0}, o1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < SB / 4; ++kk) {
+        const int k = 4 * kk + lk;
+        const double bv = M[k * MLD + lr];
+        o0 = mfma4(x_at(T, dinv, i1 + lr, i1 + k), bv, o0);
+        o1 = mfma4(x_at(T, dinv, i1 + 16 + lr, i1 + k), bv, o1);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {      // X_ip[row][col] transposed into the upper triangle
+        T[(c0 + lr) * XLD + i1 + lk + 4 * g] = -o0[g];
+        T[(c0 + lr) * XLD + i1 + 16 + lk + 4 * g] = -o1[g];
+      }
+    }
+    __syncthreads();
   }
 
-  // X = L^-1, column t by the thread pair (t, h): row i of X needs sum_{c<i} L[i][c] X[c][t];
-  // the two threads split the columns c by pair parity and meet in one lane shuffle.  X is
-  // written into the strict upper triangle of T (X[i][t] at T[t][i], i > t) and its diagonal
-  // into colb[0], so no second LDS image is needed.
-  const int t = r;
-  double *Xt = &T[t * XLD];
-  const double dt = 1.0 / Tr[t];
-  __syncthreads();
-  if (h == 0) colb[0][t] = dt;
-  for (int i = t + 1; i < TILE; ++i) {
-    const double *Li = &T[i * XLD];
-    double s = 0.0, s2 = 0.0;
-    // c = t: X[t][t] = dt (not yet in the upper triangle)
-    if (((t >> 1) & 1) == h) s = Li[t] * dt;
-    int p = (t + 1) >> 1;                   // pair holding column t+1
-    if ((p & 1) != h) ++p;
-    for (; 2 * p < i; p += 2) {
-      const int c = 2 * p;
-      const double2 l = *reinterpret_cast<const double2 *>(&Li[c]);
-      const double2 xx = *reinterpret_cast<const double2 *>(&Xt[c]);
-      if (c > t) s += l.x * xx.x;
-      if (c + 1 < i) s2 += l.y * xx.y;
-    }
-    s += s2;
-    s += __shfl_xor(s, 1, 64);
-    const double val = -s / Li[i];
-    if (h == 0) Xt[i] = val;
-    // the partner reads Xt[i] in later rows: same wave, LDS ops execute in order
-  }
-  __syncthreads();
   for (int e = tid; e < TILE * TILE; e += 256) {
     const int i = e & (TILE - 1), c = e >> 7;
-    Inv[i + TILE * c] = (i > c) ? T[c * XLD + i] : (i == c ? colb[0][i] : 0.0);
+    Inv[i + TILE * c] = x_at(T, dinv, i, c);
   }
 }
 
