@@ -145,7 +145,9 @@ int launch_k_build(hipStream_t st, const double *x, int64_t x_stride, int n, int
 // In-place lower Cholesky of `batch` padded matrices; inv_diag receives the inverses of
 // the TILE x TILE diagonal blocks ([TILE,TILE,n_pad/TILE,batch]); *d_info (device int) is
 // set non-zero when a pivot is not positive.
-int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv_diag, int *d_info);
+int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv_diag, int *d_info,
+                 hipStream_t st2 = nullptr, hipEvent_t ev_col = nullptr,
+                 hipEvent_t ev_panel = nullptr);
 // B <- S^-1 B (two blocked triangular solves) for `batch` systems sharing the layout.
 int launch_potrs(hipStream_t st, const double *L, const double *inv_diag, int n_pad, int batch,
                  double *B, int64_t ldb, int64_t strideB, int nrhs_pad);

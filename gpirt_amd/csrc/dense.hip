@@ -246,27 +246,54 @@ int launch_kstar_t(hipStream_t st, const double *x, int64_t x_stride, int n, int
 int launch_potrf_diag(hipStream_t st, double *S, int n_pad, int kb, int batch, double *inv_diag, int nb,
                       int *d_info);
 
-int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv_diag, int *d_info) {
+// Right-looking blocked Cholesky.  With a second stream the diagonal-block kernel and the
+// panel solve of step k+1 run beside the bulk of step k's trailing update (look-ahead): the
+// first block column of the update is issued on its own so that they can start early.
+int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv_diag, int *d_info,
+                 hipStream_t st2, hipEvent_t ev_col, hipEvent_t ev_panel) {
   const int nb = n_pad / TILE;
   const int64_t sS = (int64_t)n_pad * n_pad, sI = (int64_t)TILE * TILE * nb;
-  for (int k = 0; k < nb; ++k) {
-    GP_TRY(launch_potrf_diag(st, S, n_pad, k, batch, inv_diag, nb, d_info));
+  const bool ahead = st2 != nullptr && nb > 2;
+  auto panel_solve = [&](hipStream_t q, int k) -> int {   // L_ik = A_ik * inv(L_kk)^T, i > k
     int rem = nb - 1 - k;
-    if (!rem) break;
     double *panel = S + (int64_t)(k + 1) * TILE + (int64_t)n_pad * k * TILE;
-    GemmArgs p{};  // L_ik = A_ik * inv(L_kk)^T
+    GemmArgs p{};
     p.A = panel; p.lda = n_pad; p.strideA = sS;
     p.B = inv_diag + (int64_t)TILE * TILE * k; p.ldb = TILE; p.strideB = sI;
     p.C = panel; p.ldc = n_pad; p.strideC = sS;
     p.M = rem * TILE; p.N = TILE; p.K = TILE; p.batch = batch; p.alpha = 1.0; p.beta = 0.0;
-    GP_TRY(launch_gemm(st, false, true, p));
-    GemmArgs u{};  // A_ij -= L_ik L_jk^T on the lower tiles
+    return launch_gemm(q, false, true, p);
+  };
+  // A_ij -= L_ik L_jk^T for block rows/cols >= k+1+skip; only_first: just block column k+1
+  auto update = [&](hipStream_t q, int k, int skip, bool only_first) -> int {
+    int rem = nb - 1 - k - skip;
+    if (rem <= 0) return GPIRT_OK;
+    double *panel = S + (int64_t)(k + 1 + skip) * TILE + (int64_t)n_pad * k * TILE;
+    GemmArgs u{};
     u.A = panel; u.lda = n_pad; u.strideA = sS;
     u.B = panel; u.ldb = n_pad; u.strideB = sS;
-    u.C = S + (int64_t)(k + 1) * TILE * (n_pad + 1); u.ldc = n_pad; u.strideC = sS;
-    u.M = rem * TILE; u.N = rem * TILE; u.K = TILE; u.batch = batch; u.alpha = -1.0; u.beta = 1.0;
-    u.lower_only = 1;
-    GP_TRY(launch_gemm(st, false, true, u));
+    u.C = S + (int64_t)(k + 1 + skip) * TILE * (n_pad + 1); u.ldc = n_pad; u.strideC = sS;
+    u.M = rem * TILE; u.N = only_first ? TILE : rem * TILE; u.K = TILE; u.batch = batch;
+    u.alpha = -1.0; u.beta = 1.0; u.lower_only = only_first ? 0 : 1;
+    return launch_gemm(q, false, true, u);
+  };
+  GP_TRY(launch_potrf_diag(st, S, n_pad, 0, batch, inv_diag, nb, d_info));
+  if (nb > 1) GP_TRY(panel_solve(st, 0));
+  for (int k = 0; k + 1 < nb; ++k) {
+    if (!ahead) {
+      GP_TRY(update(st, k, 0, false));
+      GP_TRY(launch_potrf_diag(st, S, n_pad, k + 1, batch, inv_diag, nb, d_info));
+      if (k + 2 < nb) GP_TRY(panel_solve(st, k + 1));
+      continue;
+    }
+    GP_TRY(update(st, k, 0, true));                 // block column k+1 of the trailing matrix
+    GP_HIP(hipEventRecord(ev_col, st));
+    GP_HIP(hipStreamWaitEvent(st2, ev_col, 0));
+    GP_TRY(launch_potrf_diag(st2, S, n_pad, k + 1, batch, inv_diag, nb, d_info));
+    if (k + 2 < nb) GP_TRY(panel_solve(st2, k + 1));
+    GP_HIP(hipEventRecord(ev_panel, st2));
+    GP_TRY(update(st, k, 1, false));                // the rest, beside the work on st2
+    GP_HIP(hipStreamWaitEvent(st, ev_panel, 0));
   }
   return GPIRT_OK;
 }

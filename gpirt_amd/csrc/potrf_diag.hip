@@ -1,6 +1,7 @@
 // Diagonal-block kernel of the blocked Cholesky (chol inside mvnrnd, utils/sample_fs.m:2):
 // factor one 128x128 block and invert the factor.
 #include "common.h"
+#include <cstdlib>
 
 namespace gpirt {
 
@@ -86,7 +87,7 @@ __device__ __forceinline__ void blk_inverse_range(double (&x)[SB], const double 
 // off-diagonal blocks of the inverse follow by block substitution, again on MFMA.
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S, int n_pad, int kb,
                                                         double *__restrict__ inv_diag, int nb,
-                                                        int *__restrict__ info) {
+                                                        int *__restrict__ info, int dbg) {
   __shared__ __attribute__((aligned(16))) double T[TILE * XLD];
   __shared__ __attribute__((aligned(16))) double dinv[TILE];
   __shared__ __attribute__((aligned(16))) double ucol[SB];
@@ -96,16 +97,29 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
   double *A = S + (int64_t)n_pad * n_pad * z + (int64_t)kb * TILE * (n_pad + 1);
   double *Inv = inv_diag + (int64_t)TILE * TILE * (kb + (int64_t)nb * z);
 
-  for (int e = tid; e < TILE * TILE; e += 256) {
-    const int i = e & (TILE - 1), c = e >> 7;
-    T[i * XLD + c] = (i >= c) ? A[i + (int64_t)n_pad * c] : 0.0;
+  // block in: 16 independent 16-byte loads per thread are issued before the first is used
+  {
+    const int i2 = (tid & 63) * 2, cq = tid >> 6;       // rows i2, i2+1 of columns cq + 4*s
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      double2 v[16];
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2)
+        v[s2] = *reinterpret_cast<const double2 *>(A + i2 + (int64_t)n_pad * (cq + 4 * (s2 + 16 * half)));
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const int c = cq + 4 * (s2 + 16 * half);
+        T[i2 * XLD + c] = (i2 >= c) ? v[s2].x : 0.0;
+        T[(i2 + 1) * XLD + c] = (i2 + 1 >= c) ? v[s2].y : 0.0;
+      }
+    }
   }
   __syncthreads();
 
   for (int p = 0; p < TILE / SB; ++p) {
     const int i0 = p * SB;
     double *Tp = &T[i0 * XLD + i0];
-    if (wave == 0 && lane < SB) {
+    if (wave == 0 && lane < SB && !(dbg & 1)) {
       const int r = lane;
       double a[SB];
 #pragma unroll
@@ -129,7 +143,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
     const int R = TILE - i0 - SB;                  // rows below the diagonal block
     const int NT = R / 16;
     // panel: L_ip = A_ip * X_pp^T, a wave owns whole 16-row strips (reads before its writes)
-    for (int rb = wave; rb < NT; rb += 4) {
+    for (int rb = wave; rb < ((dbg & 2) ? 0 : NT); rb += 4) {
       const int ib = i0 + SB + 16 * rb;
       v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
     }
     __syncthreads();
     // trailing update on the lower 16x16 tiles: A_ij -= L_ip L_jp^T
-    for (int e = wave; e < NT * (NT + 1) / 2; e += 4) {
+    for (int e = wave; e < ((dbg & 2) ? 0 : NT * (NT + 1) / 2); e += 4) {
       int ti = 0;
       while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
       const int tj = e - ti * (ti + 1) / 2;
@@ -169,9 +183,14 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
   // the diagonal tiles of the trailing update also wrote their upper halves: L's strict upper
   // triangle inside each 32-block was re-zeroed by the factor step, the rest of the upper
   // triangle is where X goes next.  L back to global first.
-  for (int e = tid; e < TILE * TILE; e += 256) {
-    const int i = e & (TILE - 1), c = e >> 7;
-    A[i + (int64_t)n_pad * c] = (i >= c) ? T[i * XLD + c] : 0.0;
+  {
+    const int i2 = (tid & 63) * 2, cq = tid >> 6;
+#pragma unroll 8
+    for (int s2 = 0; s2 < 32; ++s2) {
+      const int c = cq + 4 * s2;
+      *reinterpret_cast<double2 *>(A + i2 + (int64_t)n_pad * c) =
+          make_double2(i2 >= c ? T[i2 * XLD + c] : 0.0, i2 + 1 >= c ? T[(i2 + 1) * XLD + c] : 0.0);
+    }
   }
   __syncthreads();
 
@@ -182,7 +201,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
   double *M = Ms[wave];
   for (int dlev = 1; dlev < TILE / SB; ++dlev) {
     const int ntask = 2 * (TILE / SB - dlev);
-    for (int task = wave; task < ntask; task += 4) {
+    for (int task = wave; task < ((dbg & 4) ? 0 : ntask); task += 4) {
       const int p = task >> 1, cs = task & 1, i = p + dlev;
       const int i0 = p * SB, i1 = i * SB, c0 = i0 + 16 * cs;
       v4d m0 = {0.0, 0.0, 0.0, 0.0}, m1 = {0.0, 0.0, 0.0, 0.0};
@@ -214,16 +233,22 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
     __syncthreads();
   }
 
-  for (int e = tid; e < TILE * TILE; e += 256) {
-    const int i = e & (TILE - 1), c = e >> 7;
-    Inv[i + TILE * c] = x_at(T, dinv, i, c);
+  {
+    const int i2 = (tid & 63) * 2, cq = tid >> 6;
+#pragma unroll 8
+    for (int s2 = 0; s2 < 32; ++s2) {
+      const int c = cq + 4 * s2;
+      *reinterpret_cast<double2 *>(Inv + i2 + TILE * c) =
+          make_double2(x_at(T, dinv, i2, c), x_at(T, dinv, i2 + 1, c));
+    }
   }
 }
 
 int launch_potrf_diag(hipStream_t st, double *S, int n_pad, int kb, int batch, double *inv_diag, int nb,
                       int *d_info) {
+  static int dbg = getenv("GPIRT_DIAG_DBG") ? atoi(getenv("GPIRT_DIAG_DBG")) : 0;
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, st, S, n_pad, kb, inv_diag, nb,
-                     d_info);
+                     d_info, dbg);
   GP_HIP(hipGetLastError());
   return GPIRT_OK;
 }
