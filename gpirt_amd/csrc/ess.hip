@@ -8,6 +8,7 @@
 //                     ordinal form gpirt-sythetic.R:159-167
 //   slice update      utils/elliptical_slice.m:47-102, utils/sample_fs.m:1-6
 #include "kernels.h"
+#include "phi_fast.h"
 
 namespace gpirt {
 
@@ -22,6 +23,9 @@ __global__ __launch_bounds__(64 * WPB) void loglik_unit_kernel(
     const double *__restrict__ g, int64_t ldg, const int8_t *__restrict__ y, int64_t ldy,
     const double *__restrict__ bthr, int n, int U, int C, double *__restrict__ ll_unit) {
   __shared__ double sb[WPB][MAXC + 2];
+  __shared__ double sphi[PHI_ROWS * PHI_LD];
+  phi_table_to_lds(sphi);
+  __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int u = blockIdx.x * WPB + w;
   if (u >= U) return;
@@ -31,7 +35,7 @@ __global__ __launch_bounds__(64 * WPB) void loglik_unit_kernel(
     int yy = y[r + ldy * u];
     if (yy > 0) {
       double gg = g[r + ldg * u];
-      acc += ordinal_cell_z(sb[w][yy - 1] - gg, sb[w][yy] - gg);
+      acc += ordinal_cell_fast(sb[w][yy - 1] - gg, sb[w][yy] - gg, sphi);
     }
   }
   acc = wave_sum(acc);
@@ -43,6 +47,9 @@ __global__ void loglik_row_kernel(const double *__restrict__ g, int64_t ldg,
                                   const int8_t *__restrict__ y, int64_t ldy,
                                   const double *__restrict__ bthr, int n, int U, int C,
                                   double *__restrict__ ll_row) {
+  __shared__ double sphi[PHI_ROWS * PHI_LD];
+  phi_table_to_lds(sphi);
+  __syncthreads();
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   double acc = 0.0;
@@ -52,7 +59,7 @@ __global__ void loglik_row_kernel(const double *__restrict__ g, int64_t ldg,
       const double *b = bthr + (int64_t)(C + 1) * u;
       double lo = yy == 1 ? -INFINITY : b[yy - 1], hi = yy == C ? INFINITY : b[yy];
       double gg = g[r + ldg * u];
-      acc += ordinal_cell_z(lo - gg, hi - gg);
+      acc += ordinal_cell_fast(lo - gg, hi - gg, sphi);
     }
   }
   ll_row[r] = acc;
@@ -129,7 +136,8 @@ int launch_rng_fill(hipStream_t st, uint64_t seed, uint32_t tag, uint32_t sweep,
 __device__ inline double ll_f_pass(const double *__restrict__ f, const double *__restrict__ nu,
                                    const double *__restrict__ mu, const double *__restrict__ x,
                                    double b0, double b1, double b2, const int8_t *__restrict__ y,
-                                   const double *sb, int n, int lane, double c, double s) {
+                                   const double *sb, const double *sphi, int n, int lane, double c,
+                                   double s) {
   double acc = 0.0;
   for (int r = lane; r < n; r += 64) {
     int yy = y[r];
@@ -139,7 +147,7 @@ __device__ inline double ll_f_pass(const double *__restrict__ f, const double *_
       else { double xr = x[r]; m_r = b0 + b1 * xr + b2 * xr * xr; }
       double pr = f[r] * c + nu[r] * s;
       double gg = m_r + pr;
-      acc += ordinal_cell_z(sb[yy - 1] - gg, sb[yy] - gg);
+      acc += ordinal_cell_fast(sb[yy - 1] - gg, sb[yy] - gg, sphi);
     }
   }
   return bcast0(wave_sum(acc));
@@ -147,6 +155,9 @@ __device__ inline double ll_f_pass(const double *__restrict__ f, const double *_
 
 __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
   __shared__ double sbb[WPB][MAXC + 2];
+  __shared__ double sphi[PHI_ROWS * PHI_LD];
+  phi_table_to_lds(sphi);
+  __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int u = blockIdx.x * WPB + w;
   if (u >= a.U_pad || u % a.ML >= a.mloc) return;
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
     return un ? un[d] : rng_uniform_at(a.seed, TAG_F_U, a.sweep, ug, (uint32_t)d);
   };
 
-  const double cur = ll_f_pass(f, nu, mu, x, b0, b1, b2, y, sb, n, lane, 1.0, 0.0);
+  const double cur = ll_f_pass(f, nu, mu, x, b0, b1, b2, y, sb, sphi, n, lane, 1.0, 0.0);
   const double hh = log(draw(0)) + cur;              // elliptical_slice.m:66
   double phi = draw(1) * kTwoPi;                     // :72
   double pmin = phi - kTwoPi, pmax = phi;            // :73-74
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
   double l = cur, c = 1.0, s = 0.0;
   while (r < a.R) {
     sincos(phi, &s, &c);
-    l = ll_f_pass(f, nu, mu, x, b0, b1, b2, y, sb, n, lane, c, s);  // :85-86
+    l = ll_f_pass(f, nu, mu, x, b0, b1, b2, y, sb, sphi, n, lane, c, s);  // :85-86
     ++r;
     if (l > hh) { ok = true; break; }                // :87
     if (phi > 0.0) pmax = phi;                       // :92-96
@@ -226,15 +237,15 @@ __device__ inline void params_from_white(const double *v, const double *pm, cons
 
 __device__ inline double ll_param_pass(const double *__restrict__ f, const double *__restrict__ x,
                                        double b0, double b1, double b2,
-                                       const int8_t *__restrict__ y, const double *sb, int n,
-                                       int lane) {
+                                       const int8_t *__restrict__ y, const double *sb,
+                                       const double *sphi, int n, int lane) {
   double acc = 0.0;
   for (int r = lane; r < n; r += 64) {
     int yy = y[r];
     if (yy > 0) {
       double xr = x[r];
       double gg = b0 + b1 * xr + b2 * xr * xr + f[r];
-      acc += ordinal_cell_z(sb[yy - 1] - gg, sb[yy] - gg);
+      acc += ordinal_cell_fast(sb[yy - 1] - gg, sb[yy] - gg, sphi);
     }
   }
   return bcast0(wave_sum(acc));
@@ -242,6 +253,9 @@ __device__ inline double ll_param_pass(const double *__restrict__ f, const doubl
 
 __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
   __shared__ double sbb[WPB][MAXC + 2];
+  __shared__ double sphi[PHI_ROWS * PHI_LD];
+  phi_table_to_lds(sphi);
+  __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int u = blockIdx.x * WPB + w;
   if (u >= a.U_pad || u % a.ML >= a.mloc) return;
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
   }
   double b0, b1, b2;
   params_from_white(v, pm, ps, C, b0, b1, b2, sb);
-  const double cur = ll_param_pass(f, x, b0, b1, b2, y, sb, n, lane);
+  const double cur = ll_param_pass(f, x, b0, b1, b2, y, sb, sphi, n, lane);
   int r = 0;
   bool ok = false;
   double l = cur;
@@ -286,7 +300,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
         pv[k] = rot ? v[k] * c + nv[k] * s : v[k];
       }
       params_from_white(pv, pm, ps, C, b0, b1, b2, sb);
-      l = ll_param_pass(f, x, b0, b1, b2, y, sb, n, lane);
+      l = ll_param_pass(f, x, b0, b1, b2, y, sb, sphi, n, lane);
       ++r;
       if (l > hh) { ok = true; break; }
       if (phi > 0.0) pmax = phi;

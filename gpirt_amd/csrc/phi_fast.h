@@ -1,0 +1,59 @@
+// Branch-free ordinal-probit cell for the device.
+//
+// log( Phi(zhi) - Phi(zlo) )  (log_like_fn.m:3-4 with the probit link of sigmoid_fn.m:4,
+// ordinal form gpirt-sythetic.R:159-167) from two evaluations of the upper tail
+//   Phi(-z) = exp(-z^2/2) * g(z),  z >= 0,
+// where g is read from a 64-interval table of degree-6 polynomials (phi_table.h, relative
+// error <= 5e-16 on [0,40]).  No data-dependent branch: the library erfc picks one of
+// several code paths per lane, and a wave whose lanes straddle them pays for all.
+#pragma once
+#include "common.h"
+
+#define GPIRT_PHI_QUAL static __device__ const
+#include "phi_table.h"
+
+namespace gpirt {
+
+constexpr int PHI_ROWS = GPIRT_PHI_K;
+constexpr int PHI_NC = GPIRT_PHI_DEG + 1;
+constexpr int PHI_LD = 9;   // LDS row stride (doubles): 72-byte rows spread the gathers over banks
+
+// every thread of the workgroup calls this once, followed by __syncthreads()
+__device__ inline void phi_table_to_lds(double *s) {
+  for (int e = threadIdx.x; e < PHI_ROWS * PHI_NC; e += blockDim.x)
+    s[(e / PHI_NC) * PHI_LD + (e % PHI_NC)] = kPhiTab[e];
+}
+
+__device__ inline double phi_upper(double z, const double *s) {   // Phi(-z), z >= 0
+  const double d = 1.0 + 0.5 * z;
+  double u = __builtin_amdgcn_rcp(d);
+  u = fma(u, fma(-d, u, 1.0), u);
+  u = fma(u, fma(-d, u, 1.0), u);
+  const double sc = u * (double)PHI_ROWS;
+  const int k = min((int)sc, PHI_ROWS - 1);
+  const double t = 2.0 * (sc - (double)k) - 1.0;
+  const double *c = s + k * PHI_LD;
+  double g = c[6];
+  g = fma(g, t, c[5]);
+  g = fma(g, t, c[4]);
+  g = fma(g, t, c[3]);
+  g = fma(g, t, c[2]);
+  g = fma(g, t, c[1]);
+  g = fma(g, t, c[0]);
+  const double h = -0.5 * z * z;
+  const double l = fma(-0.5 * z, z, -h);      // rounding error of h, folded back in below
+  double e = exp(h);
+  e = fma(e, l, e);
+  return e * g;
+}
+
+__device__ inline double ordinal_cell_fast(double zlo, double zhi, const double *s) {
+  zlo = fmax(zlo, -1e30);                      // +-inf thresholds: keep the arithmetic finite
+  zhi = fmin(zhi, 1e30);
+  const double e1 = phi_upper(fabs(zlo), s), e2 = phi_upper(fabs(zhi), s);
+  double p = zlo >= 0.0 ? e1 - e2 : (zhi <= 0.0 ? e2 - e1 : (1.0 - e1) - e2);
+  if (!(p > kPFloor)) p = kPFloor;
+  return log(p);
+}
+
+}  // namespace gpirt

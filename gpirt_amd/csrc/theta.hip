@@ -7,6 +7,7 @@
 // this rank's items.  All respondents advance in lock-step rounds so that, when items are
 // sharded over GPUs, one n-vector sum-all-reduce per round is the only exchange.
 #include "kernels.h"
+#include "phi_fast.h"
 
 namespace gpirt {
 
@@ -47,6 +48,9 @@ int launch_theta_prepare(hipStream_t st, const ThetaArgs &a) {
 
 // local-items log-likelihood of every active respondent, one wave per respondent
 __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initial) {
+  __shared__ double sphi[PHI_ROWS * PHI_LD];
+  phi_table_to_lds(sphi);
+  __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + w;
   if (i >= a.n) return;
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initia
         int u = jl + ML * p;
         double gg = Gr[jl] + b0[u] + b1[u] * xg + b2[u] * xg * xg;
         double lo = a.bthrS[u + (int64_t)U_pad * (yy - 1)], hi = a.bthrS[u + (int64_t)U_pad * yy];
-        acc += ordinal_cell_z(lo - gg, hi - gg);
+        acc += ordinal_cell_fast(lo - gg, hi - gg, sphi);
       }
     }
   }
