@@ -142,15 +142,31 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a);
 // strict upper triangle zero unless `full`.
 int launch_k_build(hipStream_t st, const double *x, int64_t x_stride, int n, int n_pad,
                    int batch, double ls, double sf, double jitter, double *S, bool full);
-// In-place lower Cholesky of `batch` padded matrices; inv_diag receives the inverses of
-// the TILE x TILE diagonal blocks ([TILE,TILE,n_pad/TILE,batch]); *d_info (device int) is
-// set non-zero when a pivot is not positive.
-int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv_diag, int *d_info,
-                 hipStream_t st2 = nullptr, hipEvent_t ev_col = nullptr,
+// The factor's diagonal blocks are kept inverted, in super-blocks of SUP rows: super-block c
+// of group z is a dense lower-triangular SUP x SUP matrix (ld = SUP) at
+// inv + (c + nsup*z) * SUP*SUP.  The 128 x 128 diagonal blocks come out of the Cholesky's
+// diagonal-block kernel; the off-diagonal blocks are filled in by block substitution
+// afterwards, so that the triangular solves advance SUP rows per step.
+constexpr int SUP = 4 * TILE;
+__host__ __device__ inline int inv_nsup(int n_pad) { return (n_pad / TILE + 3) / 4; }
+__host__ __device__ inline int64_t inv_group_elems(int n_pad) { return (int64_t)inv_nsup(n_pad) * SUP * SUP; }
+__host__ __device__ inline int64_t inv_block_offset(int kb) {   // 128-block kb inside its group's inverse image
+  return (int64_t)(kb / 4) * SUP * SUP + (int64_t)(kb % 4) * TILE * (SUP + 1);
+}
+// scratch the factorisation needs: 256*256 doubles per super-block and group
+inline int64_t potrf_work_elems(int n_pad, int batch) {
+  return (int64_t)inv_nsup(n_pad) * 256 * 256 * batch;
+}
+// In-place lower Cholesky of `batch` padded matrices + the inverted diagonal super-blocks
+// (inv must be zero-initialised once); *d_info (device int) is set non-zero when a pivot is
+// not positive.
+int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, int *d_info,
+                 double *work, hipStream_t st2 = nullptr, hipEvent_t ev_col = nullptr,
                  hipEvent_t ev_panel = nullptr);
-// B <- S^-1 B (two blocked triangular solves) for `batch` systems sharing the layout.
-int launch_potrs(hipStream_t st, const double *L, const double *inv_diag, int n_pad, int batch,
-                 double *B, int64_t ldb, int64_t strideB, int nrhs_pad);
+// B <- S^-1 B (two blocked triangular solves) for `batch` systems sharing the layout;
+// xtmp holds SUP * nrhs_pad doubles per system.
+int launch_potrs(hipStream_t st, const double *L, const double *inv, int n_pad, int batch,
+                 double *B, int64_t ldb, int64_t strideB, int nrhs_pad, double *xtmp);
 // Kst[r + n_pad*g] = sf^2 exp(-(xs_g - x_r)^2 / (2 ls^2)), zero outside r<n, g<G.
 int launch_kstar_t(hipStream_t st, const double *x, int64_t x_stride, int n, int n_pad, int batch,
                    double ls, double sf, int G, int G_pad, double lo, double step, double *Kst);

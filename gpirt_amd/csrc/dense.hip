@@ -182,7 +182,7 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
   // only the combinations the sweep uses are instantiated
   if (!AT && !BT && (mode == 0 || mode == 2)) return launch_gemm_mode<false, false>(st, a, mode, grid, nbm, nbn);
   if (!AT && BT && (mode == 0 || mode == 1)) return launch_gemm_mode<false, true>(st, a, mode, grid, nbm, nbn);
-  if (AT && !BT && mode == 0) return launch_gemm_mode<true, false>(st, a, mode, grid, nbm, nbn);
+  if (AT && !BT && (mode == 0 || mode == 3)) return launch_gemm_mode<true, false>(st, a, mode, grid, nbm, nbn);
   set_error("launch_gemm: combination AT=%d BT=%d mode=%d is not built", (int)AT, (int)BT, mode);
   return GPIRT_ERR_BAD_ARG;
 }
@@ -246,20 +246,53 @@ int launch_kstar_t(hipStream_t st, const double *x, int64_t x_stride, int n, int
 int launch_potrf_diag(hipStream_t st, double *S, int n_pad, int kb, int batch, double *inv_diag, int nb,
                       int *d_info);
 
+// Off-diagonal blocks of the inverted diagonal super-blocks by block substitution: for a
+// lower-triangular [[A,0],[B,C]] the inverse is [[A^-1,0],[-C^-1 B A^-1, C^-1]].
+static int build_super_inverses(hipStream_t st, const double *L, int n_pad, double *inv, double *work) {
+  const int nb = n_pad / TILE, nfull = nb / 4, tail = nb % 4;
+  // bottom = [top0+tsz, top0+tsz+bsz) gets -inv(bottom) * L[bottom, top] * inv(top), for `count`
+  // consecutive super-blocks starting at c0 (offsets in rows inside the super-block)
+  auto levelup = [&](int c0, int count, int top0, int tsz, int bsz) -> int {
+    if (count <= 0) return GPIRT_OK;
+    const int bot0 = top0 + tsz;
+    const double *Lc = L + (int64_t)c0 * SUP * (n_pad + 1);
+    double *Ic = inv + (int64_t)c0 * SUP * SUP;
+    double *Wc = work + (int64_t)c0 * 256 * 256;
+    GemmArgs t{};   // T = L[bottom, top] * inv(top)
+    t.A = Lc + bot0 + (int64_t)n_pad * top0; t.lda = n_pad; t.strideA = (int64_t)SUP * (n_pad + 1);
+    t.B = Ic + (int64_t)top0 * (SUP + 1); t.ldb = SUP; t.strideB = (int64_t)SUP * SUP;
+    t.C = Wc; t.ldc = 256; t.strideC = 256 * 256;
+    t.M = bsz; t.N = tsz; t.K = tsz; t.batch = count; t.alpha = 1.0; t.beta = 0.0;
+    GP_TRY(launch_gemm(st, false, false, t));
+    GemmArgs x{};   // inv[bottom, top] = -inv(bottom) * T
+    x.A = Ic + (int64_t)bot0 * (SUP + 1); x.lda = SUP; x.strideA = (int64_t)SUP * SUP;
+    x.B = Wc; x.ldb = 256; x.strideB = 256 * 256;
+    x.C = Ic + bot0 + (int64_t)SUP * top0; x.ldc = SUP; x.strideC = (int64_t)SUP * SUP;
+    x.M = bsz; x.N = tsz; x.K = bsz; x.batch = count; x.alpha = -1.0; x.beta = 0.0;
+    return launch_gemm(st, false, false, x);
+  };
+  GP_TRY(levelup(0, nfull, 0, TILE, TILE));
+  GP_TRY(levelup(0, nfull, 2 * TILE, TILE, TILE));
+  GP_TRY(levelup(0, nfull, 0, 2 * TILE, 2 * TILE));
+  if (tail >= 2) GP_TRY(levelup(nfull, 1, 0, TILE, TILE));
+  if (tail == 3) GP_TRY(levelup(nfull, 1, 0, 2 * TILE, TILE));
+  return GPIRT_OK;
+}
+
 // Right-looking blocked Cholesky.  With a second stream the diagonal-block kernel and the
 // panel solve of step k+1 run beside the bulk of step k's trailing update (look-ahead): the
 // first block column of the update is issued on its own so that they can start early.
-int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv_diag, int *d_info,
-                 hipStream_t st2, hipEvent_t ev_col, hipEvent_t ev_panel) {
+int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, int *d_info,
+                 double *work, hipStream_t st2, hipEvent_t ev_col, hipEvent_t ev_panel) {
   const int nb = n_pad / TILE;
-  const int64_t sS = (int64_t)n_pad * n_pad, sI = (int64_t)TILE * TILE * nb;
+  const int64_t sS = (int64_t)n_pad * n_pad, sI = inv_group_elems(n_pad);
   const bool ahead = st2 != nullptr && nb > 2;
   auto panel_solve = [&](hipStream_t q, int k) -> int {   // L_ik = A_ik * inv(L_kk)^T, i > k
     int rem = nb - 1 - k;
     double *panel = S + (int64_t)(k + 1) * TILE + (int64_t)n_pad * k * TILE;
     GemmArgs p{};
     p.A = panel; p.lda = n_pad; p.strideA = sS;
-    p.B = inv_diag + (int64_t)TILE * TILE * k; p.ldb = TILE; p.strideB = sI;
+    p.B = inv + inv_block_offset(k); p.ldb = SUP; p.strideB = sI;
     p.C = panel; p.ldc = n_pad; p.strideC = sS;
     p.M = rem * TILE; p.N = TILE; p.K = TILE; p.batch = batch; p.alpha = 1.0; p.beta = 0.0;
     return launch_gemm(q, false, true, p);
@@ -277,60 +310,73 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv_di
     u.alpha = -1.0; u.beta = 1.0; u.lower_only = only_first ? 0 : 1;
     return launch_gemm(q, false, true, u);
   };
-  GP_TRY(launch_potrf_diag(st, S, n_pad, 0, batch, inv_diag, nb, d_info));
+  GP_TRY(launch_potrf_diag(st, S, n_pad, 0, batch, inv, nb, d_info));
   if (nb > 1) GP_TRY(panel_solve(st, 0));
   for (int k = 0; k + 1 < nb; ++k) {
     if (!ahead) {
       GP_TRY(update(st, k, 0, false));
-      GP_TRY(launch_potrf_diag(st, S, n_pad, k + 1, batch, inv_diag, nb, d_info));
+      GP_TRY(launch_potrf_diag(st, S, n_pad, k + 1, batch, inv, nb, d_info));
       if (k + 2 < nb) GP_TRY(panel_solve(st, k + 1));
       continue;
     }
     GP_TRY(update(st, k, 0, true));                 // block column k+1 of the trailing matrix
     GP_HIP(hipEventRecord(ev_col, st));
     GP_HIP(hipStreamWaitEvent(st2, ev_col, 0));
-    GP_TRY(launch_potrf_diag(st2, S, n_pad, k + 1, batch, inv_diag, nb, d_info));
+    GP_TRY(launch_potrf_diag(st2, S, n_pad, k + 1, batch, inv, nb, d_info));
     if (k + 2 < nb) GP_TRY(panel_solve(st2, k + 1));
     GP_HIP(hipEventRecord(ev_panel, st2));
     GP_TRY(update(st, k, 1, false));                // the rest, beside the work on st2
     GP_HIP(hipStreamWaitEvent(st, ev_panel, 0));
   }
+  if (nb > 1)
+    for (int z = 0; z < batch; ++z)
+      GP_TRY(build_super_inverses(st, S + sS * z, n_pad, inv + sI * z,
+                                  work + (int64_t)inv_nsup(n_pad) * 256 * 256 * z));
   return GPIRT_OK;
 }
 
-int launch_potrs(hipStream_t st, const double *L, const double *inv_diag, int n_pad, int batch,
-                 double *B, int64_t ldb, int64_t strideB, int nrhs_pad) {
-  const int nb = n_pad / TILE;
-  const int64_t sS = (int64_t)n_pad * n_pad, sI = (int64_t)TILE * TILE * nb;
-  for (int k = 0; k < nb; ++k) {  // L W = B
+// Two blocked triangular solves, SUP rows per step: the diagonal step is a product with the
+// inverted super-block (written to xtmp, then copied back over B's rows), followed by one
+// rank-SUP update of the remaining rows.
+int launch_potrs(hipStream_t st, const double *L, const double *inv, int n_pad, int batch,
+                 double *B, int64_t ldb, int64_t strideB, int nrhs_pad, double *xtmp) {
+  const int nb = n_pad / TILE, nsup = inv_nsup(n_pad);
+  const int64_t sS = (int64_t)n_pad * n_pad, sI = inv_group_elems(n_pad);
+  const int64_t sX = (int64_t)SUP * nrhs_pad;
+  auto diag_step = [&](int c, int bs, bool transposed) -> int {
     GemmArgs d{};
-    d.A = inv_diag + (int64_t)TILE * TILE * k; d.lda = TILE; d.strideA = sI;
-    d.B = B + (int64_t)k * TILE; d.ldb = ldb; d.strideB = strideB;
-    d.C = B + (int64_t)k * TILE; d.ldc = ldb; d.strideC = strideB;
-    d.M = TILE; d.N = nrhs_pad; d.K = TILE; d.batch = batch; d.alpha = 1.0; d.beta = 0.0;
-    GP_TRY(launch_gemm(st, false, false, d));
-    int rem = nb - 1 - k;
-    if (!rem) break;
+    d.A = inv + (int64_t)c * SUP * SUP; d.lda = SUP; d.strideA = sI;
+    d.B = B + (int64_t)c * SUP; d.ldb = ldb; d.strideB = strideB;
+    d.C = xtmp; d.ldc = SUP; d.strideC = sX;
+    d.M = bs; d.N = nrhs_pad; d.K = bs; d.batch = batch; d.alpha = 1.0; d.beta = 0.0;
+    d.k_trim = transposed ? 2 : 1;
+    GP_TRY(launch_gemm(st, transposed, false, d));
+    for (int z = 0; z < batch; ++z)
+      GP_HIP(hipMemcpy2DAsync(B + strideB * z + (int64_t)c * SUP, sizeof(double) * ldb, xtmp + sX * z,
+                              sizeof(double) * SUP, sizeof(double) * bs, nrhs_pad,
+                              hipMemcpyDeviceToDevice, st));
+    return GPIRT_OK;
+  };
+  for (int c = 0; c < nsup; ++c) {          // L W = B
+    const int bs = min(4, nb - 4 * c) * TILE, r0 = c * SUP, below = n_pad - r0 - bs;
+    GP_TRY(diag_step(c, bs, false));
+    if (below <= 0) break;
     GemmArgs u{};
-    u.A = L + (int64_t)(k + 1) * TILE + (int64_t)n_pad * k * TILE; u.lda = n_pad; u.strideA = sS;
-    u.B = B + (int64_t)k * TILE; u.ldb = ldb; u.strideB = strideB;
-    u.C = B + (int64_t)(k + 1) * TILE; u.ldc = ldb; u.strideC = strideB;
-    u.M = rem * TILE; u.N = nrhs_pad; u.K = TILE; u.batch = batch; u.alpha = -1.0; u.beta = 1.0;
+    u.A = L + (r0 + bs) + (int64_t)n_pad * r0; u.lda = n_pad; u.strideA = sS;
+    u.B = B + r0; u.ldb = ldb; u.strideB = strideB;
+    u.C = B + r0 + bs; u.ldc = ldb; u.strideC = strideB;
+    u.M = below; u.N = nrhs_pad; u.K = bs; u.batch = batch; u.alpha = -1.0; u.beta = 1.0;
     GP_TRY(launch_gemm(st, false, false, u));
   }
-  for (int k = nb - 1; k >= 0; --k) {  // L' X = W
-    GemmArgs d{};
-    d.A = inv_diag + (int64_t)TILE * TILE * k; d.lda = TILE; d.strideA = sI;
-    d.B = B + (int64_t)k * TILE; d.ldb = ldb; d.strideB = strideB;
-    d.C = B + (int64_t)k * TILE; d.ldc = ldb; d.strideC = strideB;
-    d.M = TILE; d.N = nrhs_pad; d.K = TILE; d.batch = batch; d.alpha = 1.0; d.beta = 0.0;
-    GP_TRY(launch_gemm(st, true, false, d));
-    if (!k) break;
-    GemmArgs u{};  // B_i -= L_ki^T B_k for i < k
-    u.A = L + (int64_t)k * TILE; u.lda = n_pad; u.strideA = sS;
-    u.B = B + (int64_t)k * TILE; u.ldb = ldb; u.strideB = strideB;
+  for (int c = nsup - 1; c >= 0; --c) {     // L' X = W
+    const int bs = min(4, nb - 4 * c) * TILE, r0 = c * SUP;
+    GP_TRY(diag_step(c, bs, true));
+    if (!c) break;
+    GemmArgs u{};  // B_above -= L[block c, above]^T B_c
+    u.A = L + r0; u.lda = n_pad; u.strideA = sS;
+    u.B = B + r0; u.ldb = ldb; u.strideB = strideB;
     u.C = B; u.ldc = ldb; u.strideC = strideB;
-    u.M = k * TILE; u.N = nrhs_pad; u.K = TILE; u.batch = batch; u.alpha = -1.0; u.beta = 1.0;
+    u.M = r0; u.N = nrhs_pad; u.K = bs; u.batch = batch; u.alpha = -1.0; u.beta = 1.0;
     GP_TRY(launch_gemm(st, true, false, u));
   }
   return GPIRT_OK;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
   const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double *A = S + (int64_t)n_pad * n_pad * z + (int64_t)kb * TILE * (n_pad + 1);
-  double *Inv = inv_diag + (int64_t)TILE * TILE * (kb + (int64_t)nb * z);
+  double *Inv = inv_diag + inv_group_elems(n_pad) * z + inv_block_offset(kb);   // ld = SUP
 
   // block in: 16 independent 16-byte loads per thread are issued before the first is used
   {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
 #pragma unroll 8
     for (int s2 = 0; s2 < 32; ++s2) {
       const int c = cq + 4 * s2;
-      *reinterpret_cast<double2 *>(Inv + i2 + TILE * c) =
+      *reinterpret_cast<double2 *>(Inv + i2 + SUP * c) =
           make_double2(x_at(T, dinv, i2, c), x_at(T, dinv, i2 + 1, c));
     }
   }

@@ -98,7 +98,7 @@ struct gpirt_sampler {
   hipStream_t st, st2;          // st2 + the two events carry the Cholesky look-ahead
   hipEvent_t ev_col, ev_panel;
   int8_t *d_y, *d_yT;
-  double *d_theta, *d_f, *d_Z, *d_nu, *d_S, *d_inv, *d_W, *d_Gt;
+  double *d_theta, *d_f, *d_Z, *d_nu, *d_S, *d_inv, *d_fwork, *d_xtmp, *d_W, *d_Gt;
   double *d_ebeta, *d_delta, *d_beta, *d_bthr, *d_betaS, *d_bthrS, *d_bpm, *d_bps;
   double *d_xc, *d_tnu, *d_prop, *d_hh, *d_phi, *d_pmin, *d_pmax, *d_buf, *d_Lt, *d_tpm, *d_tps;
   double *d_llu;
@@ -115,7 +115,7 @@ struct gpirt_sampler {
 
 static void sampler_free(gpirt_sampler *s) {
   if (!s) return;
-  void *ptrs[] = {s->d_y, s->d_yT, s->d_theta, s->d_f, s->d_Z, s->d_nu, s->d_S, s->d_inv, s->d_W,
+  void *ptrs[] = {s->d_y, s->d_yT, s->d_theta, s->d_f, s->d_Z, s->d_nu, s->d_S, s->d_inv, s->d_fwork, s->d_xtmp, s->d_W,
                   s->d_Gt, s->d_ebeta, s->d_delta, s->d_beta, s->d_bthr, s->d_betaS, s->d_bthrS,
                   s->d_bpm, s->d_bps, s->d_xc, s->d_tnu, s->d_prop, s->d_hh, s->d_phi, s->d_pmin,
                   s->d_pmax, s->d_buf, s->d_Lt, s->d_tpm, s->d_tps, s->d_llu, s->d_done, s->d_info,
@@ -251,7 +251,9 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   A_(s->d_Z, (size_t)Np_pad * U_pad);
   A_(s->d_nu, (size_t)Np_pad * U_pad);
   A_(s->d_S, (size_t)Np_pad * Np_pad * P);
-  A_(s->d_inv, (size_t)TILE * TILE * s->nb * P);
+  A_(s->d_inv, (size_t)inv_group_elems(Np_pad) * P);
+  A_(s->d_fwork, (size_t)potrf_work_elems(Np_pad, P));
+  A_(s->d_xtmp, (size_t)SUP * G_pad * P);
   A_(s->d_W, (size_t)Np_pad * G_pad * P);
   A_(s->d_Gt, (size_t)U_pad * G_pad);
   A_(s->d_ebeta, 3 * (size_t)U_pad);
@@ -374,8 +376,8 @@ static int phase_factor(gpirt_sampler *s) {
                           s->cfg.irf_sf, s->jitter_now, s->d_S, false));
     GP_TRY(mark(s, PH_POTRF));
     GP_HIP(hipMemsetAsync(s->d_info, 0, sizeof(int), s->st));
-    GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info, s->st2, s->ev_col,
-                        s->ev_panel));
+    GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info, s->d_fwork, s->st2,
+                        s->ev_col, s->ev_panel));
     int info = 0;
     GP_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, s->st));
     GP_HIP(hipStreamSynchronize(s->st));
@@ -432,7 +434,7 @@ static int phase_fstar(gpirt_sampler *s) {
   GP_TRY(launch_kstar_t(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
                         s->cfg.irf_sf, s->G, s->G_pad, s->cfg.grid_lo, s->cfg.grid_step, s->d_W));
   GP_TRY(launch_potrs(s->st, s->d_S, s->d_inv, s->Np_pad, s->P, s->d_W, s->Np_pad,
-                      (int64_t)s->Np_pad * s->G_pad, s->G_pad));
+                      (int64_t)s->Np_pad * s->G_pad, s->G_pad, s->d_xtmp));
   GemmArgs g{};
   g.A = s->d_f; g.lda = s->Np_pad; g.strideA = (int64_t)s->Np_pad * s->ML;
   g.B = s->d_W; g.ldb = s->Np_pad; g.strideB = (int64_t)s->Np_pad * s->G_pad;
@@ -694,13 +696,14 @@ static int upload_spd_padded(const double *S, int n, int np, double *d) {
 int gpirt_potrf(const double *S, int32_t n, double *L) {
   if (!S || !L || n < 1) { set_error("gpirt_potrf: bad argument"); return GPIRT_ERR_BAD_ARG; }
   GP_TRY(have_device());
-  const int np = (int)pad_up(n), nb = np / TILE;
-  DevBuf dS, dI, dinfo;
+  const int np = (int)pad_up(n);
+  DevBuf dS, dI, dinfo, dwork;
   GP_TRY(dS.alloc(sizeof(double) * (size_t)np * np, false));
-  GP_TRY(dI.alloc(sizeof(double) * (size_t)TILE * TILE * nb));
+  GP_TRY(dI.alloc(sizeof(double) * (size_t)inv_group_elems(np)));
+  GP_TRY(dwork.alloc(sizeof(double) * (size_t)potrf_work_elems(np, 1)));
   GP_TRY(dinfo.alloc(sizeof(int)));
   GP_TRY(upload_spd_padded(S, n, np, dS.as<double>()));
-  GP_TRY(launch_potrf(0, dS.as<double>(), np, 1, dI.as<double>(), dinfo.as<int>()));
+  GP_TRY(launch_potrf(0, dS.as<double>(), np, 1, dI.as<double>(), dinfo.as<int>(), dwork.as<double>()));
   int info = 0;
   GP_HIP(hipMemcpy(&info, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
   GP_TRY(download_padded(L, n, n, dS.as<double>(), np, 0));
@@ -733,18 +736,18 @@ int gpirt_trmm_lz(const double *L, const double *Z, int32_t n, int32_t k, double
 // device factor + diagonal-block inverses from a host factor (re-derives the inverses by
 // factoring L L^T's diagonal blocks is not possible without S, so S = L L^T is rebuilt)
 static int factor_from_host_L(const double *L, int n, int np, DevBuf &dS, DevBuf &dI) {
-  const int nb = np / TILE;
-  DevBuf dL, dinfo;
+  DevBuf dL, dinfo, dwork;
   GP_TRY(dL.alloc(sizeof(double) * (size_t)np * np));
   GP_TRY(dS.alloc(sizeof(double) * (size_t)np * np));
-  GP_TRY(dI.alloc(sizeof(double) * (size_t)TILE * TILE * nb));
+  GP_TRY(dI.alloc(sizeof(double) * (size_t)inv_group_elems(np)));
+  GP_TRY(dwork.alloc(sizeof(double) * (size_t)potrf_work_elems(np, 1)));
   GP_TRY(dinfo.alloc(sizeof(int)));
   GP_TRY(upload_spd_padded(L, n, np, dL.as<double>()));
   GemmArgs g{};  // S = L L^T
   g.A = dL.as<double>(); g.lda = np; g.B = dL.as<double>(); g.ldb = np; g.C = dS.as<double>();
   g.ldc = np; g.M = np; g.N = np; g.K = np; g.batch = 1; g.alpha = 1.0; g.beta = 0.0;
   GP_TRY(launch_gemm(0, false, true, g));
-  GP_TRY(launch_potrf(0, dS.as<double>(), np, 1, dI.as<double>(), dinfo.as<int>()));
+  GP_TRY(launch_potrf(0, dS.as<double>(), np, 1, dI.as<double>(), dinfo.as<int>(), dwork.as<double>()));
   int info = 0;
   GP_HIP(hipMemcpy(&info, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
   if (info) { set_error("L L^T is not positive definite (pivot %d)", info); return GPIRT_ERR_NOT_PD; }
@@ -755,11 +758,13 @@ int gpirt_potrs(const double *L, const double *B, int32_t n, int32_t k, double *
   if (!L || !B || !X || n < 1 || k < 1) { set_error("gpirt_potrs: bad argument"); return GPIRT_ERR_BAD_ARG; }
   GP_TRY(have_device());
   const int np = (int)pad_up(n), kp = (int)pad_up(k);
-  DevBuf dS, dI, dB;
+  DevBuf dS, dI, dB, dX;
   GP_TRY(factor_from_host_L(L, n, np, dS, dI));
   GP_TRY(dB.alloc(sizeof(double) * (size_t)np * kp));
+  GP_TRY(dX.alloc(sizeof(double) * (size_t)SUP * kp));
   GP_TRY(upload_padded(B, n, k, dB.as<double>(), np, 0));
-  GP_TRY(launch_potrs(0, dS.as<double>(), dI.as<double>(), np, 1, dB.as<double>(), np, 0, kp));
+  GP_TRY(launch_potrs(0, dS.as<double>(), dI.as<double>(), np, 1, dB.as<double>(), np, 0, kp,
+                      dX.as<double>()));
   GP_TRY(download_padded(X, n, k, dB.as<double>(), np, 0));
   GP_HIP(hipDeviceSynchronize());
   return GPIRT_OK;
@@ -832,8 +837,9 @@ int gpirt_fstar_predict(const double *x, const double *L, const double *f, int32
   }
   GP_TRY(have_device());
   const int np = (int)pad_up(n), up = (int)pad_up(u), gp = (int)pad_up(n_grid);
-  DevBuf dS, dI, dx, dW, dF, dGt, dout;
+  DevBuf dS, dI, dx, dW, dF, dGt, dout, dX;
   GP_TRY(factor_from_host_L(L, n, np, dS, dI));
+  GP_TRY(dX.alloc(sizeof(double) * (size_t)SUP * gp));
   GP_TRY(dx.alloc(sizeof(double) * n));
   GP_TRY(dW.alloc(sizeof(double) * (size_t)np * gp));
   GP_TRY(dF.alloc(sizeof(double) * (size_t)np * up));
@@ -843,7 +849,8 @@ int gpirt_fstar_predict(const double *x, const double *L, const double *f, int32
   GP_TRY(upload_padded(f, n, u, dF.as<double>(), np, 0));
   GP_TRY(launch_kstar_t(0, dx.as<double>(), 0, n, np, 1, ls, sf, n_grid, gp, grid_lo, grid_step,
                         dW.as<double>()));
-  GP_TRY(launch_potrs(0, dS.as<double>(), dI.as<double>(), np, 1, dW.as<double>(), np, 0, gp));
+  GP_TRY(launch_potrs(0, dS.as<double>(), dI.as<double>(), np, 1, dW.as<double>(), np, 0, gp,
+                      dX.as<double>()));
   GemmArgs g{};
   g.A = dF.as<double>(); g.lda = np; g.B = dW.as<double>(); g.ldb = np; g.C = dGt.as<double>();
   g.ldc = up; g.M = up; g.N = gp; g.K = np; g.batch = 1; g.alpha = 1.0; g.beta = 0.0;
