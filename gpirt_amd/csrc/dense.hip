@@ -6,6 +6,7 @@
 //   nu = L z               utils/elliptical_slice.m:64
 //   S^-1 B                 the solve inside gp(...), main.m:57-58
 #include "common.h"
+#include <cstdlib>
 
 namespace gpirt {
 
@@ -77,18 +78,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
   const int z = blockIdx.y;
   const double *__restrict__ A = g.A + g.strideA * z;
   const double *__restrict__ B = g.B + g.strideB * z;
-  double *__restrict__ C = g.C + g.strideC * z;
+  double *C = g.C + g.strideC * z;   // may alias A or B (in-place panel and solve steps)
   const int i0 = bi * TILE, j0 = bj * TILE;
   int kbeg = 0, kend = g.K;
   if (MODE == 2) kend = min(g.K, (bi + 1) * TILE);
   if (MODE == 3) kbeg = bi * TILE;
   const int64_t lda = g.lda, ldb = g.ldb;
 
+  const int wm0 = (wave & 1) * 64, wn0 = (wave >> 1) * 64;
+  const int lr = lane & 15, lk = lane >> 4;
+  const double alpha = g.alpha, beta = g.beta;
+  const int64_t ldc = g.ldc;
+  // C enters through the accumulators (acc = beta/alpha * C, result = alpha * acc): its read
+  // overlaps the first operand loads instead of trailing the last MFMA
   v4d acc[4][4];
+  if (beta != 0.0) {
+    const double sc = beta / alpha;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[tj][ti][r] = sc * C[(i0 + wm0 + ti * 16 + lr) + ldc * (int64_t)(j0 + wn0 + tj * 16 + lk + 4 * r)];
+  } else {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
 
   double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
   TILE_LOAD(AT, A, lda, i0, kbeg, ra);
@@ -97,8 +115,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
   TILE_STORE(!BT, sB[0], rb);
   __syncthreads();
 
-  const int wm0 = (wave & 1) * 64, wn0 = (wave >> 1) * 64;
-  const int lr = lane & 15, lk = lane >> 4;
   const int klast = kend - BK;
   int buf = 0;
   // single-block loop body: the prefetch of the slab after the last one re-reads the last
@@ -139,8 +155,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
     buf ^= 1;
   }
 
-  const double alpha = g.alpha, beta = g.beta;
-  const int64_t ldc = g.ldc;
 #pragma unroll
   for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
@@ -149,10 +163,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
       for (int r = 0; r < 4; ++r) {
         int j = j0 + wn0 + tj * 16 + lk + 4 * r;
         int i = i0 + wm0 + ti * 16 + lr;
-        double *c = C + i + ldc * (int64_t)j;
-        double v = alpha * acc[tj][ti][r];
-        if (beta != 0.0) v += beta * *c;
-        *c = v;
+        C[i + ldc * (int64_t)j] = alpha * acc[tj][ti][r];
       }
 }
 
@@ -286,7 +297,11 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
                  double *work, hipStream_t st2, hipEvent_t ev_col, hipEvent_t ev_panel) {
   const int nb = n_pad / TILE;
   const int64_t sS = (int64_t)n_pad * n_pad, sI = inv_group_elems(n_pad);
-  const bool ahead = st2 != nullptr && nb > 2;
+  // measured: the one-workgroup diagonal kernel needs a whole CU's LDS, so beside a trailing
+  // update that fills every CU it only starts when that update drains; the look-ahead path
+  // is kept for experiments (GPIRT_LOOKAHEAD=1) but is not faster
+  static const bool want_ahead = getenv("GPIRT_LOOKAHEAD") != nullptr;
+  const bool ahead = st2 != nullptr && nb > 2 && want_ahead;
   auto panel_solve = [&](hipStream_t q, int k) -> int {   // L_ik = A_ik * inv(L_kk)^T, i > k
     int rem = nb - 1 - k;
     double *panel = S + (int64_t)(k + 1) * TILE + (int64_t)n_pad * k * TILE;
@@ -310,6 +325,38 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
     u.alpha = -1.0; u.beta = 1.0; u.lower_only = only_first ? 0 : 1;
     return launch_gemm(q, false, true, u);
   };
+  if (!ahead) {
+    // two-level blocking: a super-panel of 4 block columns is factored by 128-wide steps whose
+    // updates stay inside the panel; the trailing matrix then gets ONE rank-512 update, which
+    // cuts the read-modify-write traffic on it four-fold
+    auto update_rect = [&](int k, int c0, int c1) -> int {   // cols [c0,c1) by panel k, rows >= c0
+      if (c1 <= c0) return GPIRT_OK;
+      GemmArgs u{};
+      u.A = S + (int64_t)c0 * TILE + (int64_t)n_pad * k * TILE; u.lda = n_pad; u.strideA = sS;
+      u.B = u.A; u.ldb = n_pad; u.strideB = sS;
+      u.C = S + (int64_t)c0 * TILE * (n_pad + 1); u.ldc = n_pad; u.strideC = sS;
+      u.M = (nb - c0) * TILE; u.N = (c1 - c0) * TILE; u.K = TILE; u.batch = batch;
+      u.alpha = -1.0; u.beta = 1.0;
+      return launch_gemm(st, false, true, u);
+    };
+    for (int o = 0; o < nb; o += 4) {
+      const int oe = min(o + 4, nb);
+      for (int k = o; k < oe; ++k) {
+        GP_TRY(launch_potrf_diag(st, S, n_pad, k, batch, inv, nb, d_info));
+        if (k + 1 < nb) GP_TRY(panel_solve(st, k));
+        GP_TRY(update_rect(k, k + 1, oe));
+      }
+      if (oe < nb) {
+        GemmArgs u{};
+        u.A = S + (int64_t)oe * TILE + (int64_t)n_pad * o * TILE; u.lda = n_pad; u.strideA = sS;
+        u.B = u.A; u.ldb = n_pad; u.strideB = sS;
+        u.C = S + (int64_t)oe * TILE * (n_pad + 1); u.ldc = n_pad; u.strideC = sS;
+        u.M = (nb - oe) * TILE; u.N = u.M; u.K = (oe - o) * TILE; u.batch = batch;
+        u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
+        GP_TRY(launch_gemm(st, false, true, u));
+      }
+    }
+  } else {
   GP_TRY(launch_potrf_diag(st, S, n_pad, 0, batch, inv, nb, d_info));
   if (nb > 1) GP_TRY(panel_solve(st, 0));
   for (int k = 0; k + 1 < nb; ++k) {
@@ -327,6 +374,7 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
     GP_HIP(hipEventRecord(ev_panel, st2));
     GP_TRY(update(st, k, 1, false));                // the rest, beside the work on st2
     GP_HIP(hipStreamWaitEvent(st, ev_panel, 0));
+  }
   }
   if (nb > 1)
     for (int z = 0; z < batch; ++z)

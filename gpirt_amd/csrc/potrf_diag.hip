@@ -40,9 +40,12 @@ __device__ __forceinline__ void blk_factor_step(double (&a)[SB], double *ucol, d
   const double w = a[J] * (y * y);        // A[r][J] / d
   a[J] = a[J] * y;                        // L[r][J]
   if (r == J) dinv_p[J] = y;
+  double uc[SB];                          // all pivot-column reads in flight before the first use
+#pragma unroll
+  for (int c = J + 1; c < SB; ++c) uc[c] = ucol[c];
 #pragma unroll
   for (int c = J + 1; c < SB; ++c) {
-    a[c] -= w * ucol[c];
+    a[c] -= w * uc[c];
     // pin the update to this step: left alone, the compiler defers every update that the
     // next pivot does not need and keeps w and the pivot column of all 32 steps alive
     asm volatile("" : "+v"(a[c]));
