@@ -31,6 +31,22 @@ def dense_flops(n, m, G):
     return dict(potrf=n ** 3 / 3.0, nu=float(n) * n * m, fstar=2.0 * n * n * m + 2.0 * G * n * m)
 
 
+def pmc_traffic(n, m, world):
+    """HBM bytes per launch of the nu = L*Z kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE doubled as the gfx950 correction asks, plus WRITE_SIZE); counters cannot be
+    read from inside this process, so the figure is the one recorded under profiles/ for the
+    same configuration, or None when the configuration differs."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_nu_gemm.json")
+    try:
+        rec = json.load(open(path))
+    except OSError:
+        return None
+    c = rec.get("config", {})
+    if (c.get("n"), c.get("m"), c.get("n_gpus")) != (n, m, world):
+        return None
+    return rec["hbm_bytes_per_launch"]
+
+
 def cpu_baseline(args, n_full, m_full, G):
     """Time the CPU oracle on a bounded sample of the same workload and scale each phase by
     its own cost law to the full configuration."""
@@ -171,10 +187,11 @@ def main():
                                    "1001-point grid, thresholds and beta sampled" % (n, m, C),
                        "items_per_gpu": mloc, "parallelism": "items sharded x%d" % world},
             "roofline": {
-                "kernel": "gemm_f64_kernel<false,false> as nu = L*Z (one launch per sweep)",
+                "kernel": "gemm_f64_kernel<false,false,4> (nu = L*Z, one launch per sweep)",
                 "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "flop_per_launch": fl["nu"], "ms_per_launch": nu_ms, "traffic": None,
+                "flop_per_launch": fl["nu"], "ms_per_launch": nu_ms,
+                "traffic": pmc_traffic(n, m, world),
             },
             "phases_ms": phases,
             "launch_marks_per_step": launches,

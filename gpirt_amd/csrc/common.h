@@ -132,6 +132,7 @@ struct GemmArgs {
   int lower_only;    // compute only tiles with row-block >= col-block (C square)
   int k_trim;        // 1: A is lower-triangular => K range of row-block bi is [0,(bi+1)*TILE)
                      // 2: A^T is used with A lower-triangular => K range is [bi*TILE, K)
+                     // 3: as 1, instantiated under its own kernel name (the nu = L*Z launch)
 };
 // C = alpha * op(A) * op(B) + beta * C.
 //   AT = false: A(i,k) at A[i + lda*k];  AT = true: A(i,k) at A[k + lda*i]

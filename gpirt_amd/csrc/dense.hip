@@ -58,7 +58,8 @@ __device__ __forceinline__ void slab_st(double (*s)[LDS_LD], int tid, int p, dou
   slab_st<KC>(s, tid, 3, r##3)
 
 // MODE: 0 plain, 1 lower tiles only (C square), 2 A lower-triangular (K range of row-block
-// bi is [0,(bi+1)*TILE)), 3 A^T with A lower-triangular (K range [bi*TILE, K)).
+// bi is [0,(bi+1)*TILE)), 3 A^T with A lower-triangular (K range [bi*TILE, K)), 4 = 2 under
+// a name of its own for the once-per-sweep nu = L*Z launch (so that a profile lists it apart).
 template <bool AT, bool BT, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, int nbn) {
   __shared__ double sA[2][BK][LDS_LD];
@@ -70,6 +71,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
     while ((int64_t)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
     while ((int64_t)bi * (bi + 1) / 2 > t) --bi;
     bj = t - (int)((int64_t)bi * (bi + 1) / 2);
+  } else if (MODE == 4) {
+    // XCD-aware order.  Workgroups are dealt round-robin over the 8 XCDs, so t % 8 names the
+    // XCD's share: each share walks 8x4 super-tiles, whose 32 tiles run together on that XCD
+    // and stream the same 8 row panels of A and 4 column panels of B through its L2.
+    // Longest K (largest bi) first.
+    const int x = t & 7, q = t >> 3;
+    const int sup = (q >> 5) * 8 + x, inner = q & 31;
+    const int nsj = (nbn + 3) / 4;
+    const int sbi = sup / nsj, sbj = sup % nsj;
+    bi = nbm - 1 - (sbi * 8 + (inner >> 2));
+    bj = sbj * 4 + (inner & 3);
+    if (bi < 0 || bj >= nbn) return;
   } else if (MODE == 2) {   // longest K first
     bi = nbm - 1 - t / nbn; bj = t % nbn;
   } else {
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
   double *C = g.C + g.strideC * z;   // may alias A or B (in-place panel and solve steps)
   const int i0 = bi * TILE, j0 = bj * TILE;
   int kbeg = 0, kend = g.K;
-  if (MODE == 2) kend = min(g.K, (bi + 1) * TILE);
+  if (MODE == 2 || MODE == 4) kend = min(g.K, (bi + 1) * TILE);
   if (MODE == 3) kbeg = bi * TILE;
   const int64_t lda = g.lda, ldb = g.ldb;
 
@@ -174,6 +187,7 @@ static int launch_gemm_mode(hipStream_t st, const GemmArgs &a, int mode, dim3 gr
     case 0: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, 0>), grid, block, 0, st, a, nbm, nbn); break;
     case 1: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, 1>), grid, block, 0, st, a, nbm, nbn); break;
     case 2: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, 2>), grid, block, 0, st, a, nbm, nbn); break;
+    case 4: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, 4>), grid, block, 0, st, a, nbm, nbn); break;
     default: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, 3>), grid, block, 0, st, a, nbm, nbn); break;
   }
   GP_HIP(hipGetLastError());
@@ -187,11 +201,15 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
     return GPIRT_ERR_BAD_ARG;
   }
   int nbm = a.M / TILE, nbn = a.N / TILE;
-  int mode = a.lower_only ? 1 : (a.k_trim == 1 ? 2 : (a.k_trim == 2 ? 3 : 0));
+  int mode = a.lower_only ? 1 : (a.k_trim == 1 ? 2 : (a.k_trim == 2 ? 3 : (a.k_trim == 3 ? 4 : 0)));
   int64_t tiles = a.lower_only ? (int64_t)nbm * (nbm + 1) / 2 : (int64_t)nbm * nbn;
+  if (mode == 4) {   // whole 8x4 super-tiles, a multiple of 8 of them (one share per XCD)
+    int64_t nsup = (int64_t)((nbm + 7) / 8) * ((nbn + 3) / 4);
+    tiles = (nsup + 7) / 8 * 8 * 32;
+  }
   dim3 grid((unsigned)tiles, (unsigned)a.batch);
   // only the combinations the sweep uses are instantiated
-  if (!AT && !BT && (mode == 0 || mode == 2)) return launch_gemm_mode<false, false>(st, a, mode, grid, nbm, nbn);
+  if (!AT && !BT && (mode == 0 || mode == 2 || mode == 4)) return launch_gemm_mode<false, false>(st, a, mode, grid, nbm, nbn);
   if (!AT && BT && (mode == 0 || mode == 1)) return launch_gemm_mode<false, true>(st, a, mode, grid, nbm, nbn);
   if (AT && !BT && (mode == 0 || mode == 3)) return launch_gemm_mode<true, false>(st, a, mode, grid, nbm, nbn);
   set_error("launch_gemm: combination AT=%d BT=%d mode=%d is not built", (int)AT, (int)BT, mode);

@@ -401,7 +401,7 @@ static int phase_f(gpirt_sampler *s) {
   g.B = s->d_Z; g.ldb = s->Np_pad; g.strideB = (int64_t)s->Np_pad * s->ML;
   g.C = s->d_nu; g.ldc = s->Np_pad; g.strideC = (int64_t)s->Np_pad * s->ML;
   g.M = s->Np_pad; g.N = s->ML; g.K = s->Np_pad; g.batch = s->P; g.alpha = 1.0; g.beta = 0.0;
-  g.k_trim = 1;
+  g.k_trim = 3;
   GP_TRY(launch_gemm(s->st, false, false, g));
   GP_TRY(mark(s, PH_ESSF));
   EssFArgs a{};
