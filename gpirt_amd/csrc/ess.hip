@@ -131,15 +131,32 @@ int launch_rng_fill(hipStream_t st, uint64_t seed, uint32_t tag, uint32_t sweep,
 }
 
 // ---------------------------------------------------------------------------------------
-// slice update of f, one wave per unit (a4 + a5)
+// A unit is owned either by one wave (WPU = 1, four units per workgroup) or, when it has
+// many rows, by the four waves of a workgroup (WPU = 4): units need different numbers of
+// likelihood evaluations, and with one workgroup per unit the dispatcher evens that out
+// instead of leaving the longest unit of each SIMD as a tail.
 // ---------------------------------------------------------------------------------------
+template <int WPU>
+__device__ inline double unit_sum(double acc, double *red, int w) {
+  const double v = wave_sum(acc);
+  if (WPU == 1) return bcast0(v);
+  __syncthreads();                       // everyone is done with the previous sums
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);   // fixed order: identical in every wave
+}
+
+// ---------------------------------------------------------------------------------------
+// slice update of f (a4 + a5)
+// ---------------------------------------------------------------------------------------
+template <int WPU>
 __device__ inline double ll_f_pass(const double *__restrict__ f, const double *__restrict__ nu,
                                    const double *__restrict__ mu, const double *__restrict__ x,
                                    double b0, double b1, double b2, const int8_t *__restrict__ y,
-                                   const double *sb, const double *sphi, int n, int lane, double c,
-                                   double s) {
+                                   const double *sb, const double *sphi, int n, int row0, double c,
+                                   double s, double *red, int w) {
   double acc = 0.0;
-  for (int r = lane; r < n; r += 64) {
+  for (int r = row0; r < n; r += 64 * WPU) {
     int yy = y[r];
     if (yy > 0) {
       double m_r;
@@ -150,21 +167,25 @@ __device__ inline double ll_f_pass(const double *__restrict__ f, const double *_
       acc += ordinal_cell_fast(sb[yy - 1] - gg, sb[yy] - gg, sphi);
     }
   }
-  return bcast0(wave_sum(acc));
+  return unit_sum<WPU>(acc, red, w);
 }
 
+template <int WPU>
 __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
   __shared__ double sbb[WPB][MAXC + 2];
   __shared__ double sphi[PHI_ROWS * PHI_LD];
+  __shared__ double red[WPB];
   phi_table_to_lds(sphi);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int u = blockIdx.x * WPB + w;
-  if (u >= a.U_pad || u % a.ML >= a.mloc) return;
-  double *sb = sbb[w];
+  const int u = WPU == 1 ? blockIdx.x * WPB + w : blockIdx.x;
+  if (u >= a.U_pad || u % a.ML >= a.mloc) return;    // uniform over the workgroup when WPU = 4
+  double *sb = sbb[WPU == 1 ? w : 0];
   const int C = a.C, n = a.Np;
-  if (lane <= C)
+  const int row0 = WPU == 1 ? lane : lane + 64 * w;
+  if ((WPU == 1 || w == 0) && lane <= C)
     sb[lane] = lane == 0 ? -INFINITY : (lane == C ? INFINITY : a.bthr[lane + (int64_t)(C + 1) * u]);
+  if (WPU != 1) __syncthreads();
   double *f = a.f + a.ld * u;
   const double *nu = a.nu + a.ld * u;
   const double *mu = a.mu ? a.mu + a.ld_mu * u : nullptr;
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
     return un ? un[d] : rng_uniform_at(a.seed, TAG_F_U, a.sweep, ug, (uint32_t)d);
   };
 
-  const double cur = ll_f_pass(f, nu, mu, x, b0, b1, b2, y, sb, sphi, n, lane, 1.0, 0.0);
+  const double cur = ll_f_pass<WPU>(f, nu, mu, x, b0, b1, b2, y, sb, sphi, n, row0, 1.0, 0.0, red, w);
   const double hh = log(draw(0)) + cur;              // elliptical_slice.m:66
   double phi = draw(1) * kTwoPi;                     // :72
   double pmin = phi - kTwoPi, pmax = phi;            // :73-74
@@ -187,7 +208,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
   double l = cur, c = 1.0, s = 0.0;
   while (r < a.R) {
     sincos(phi, &s, &c);
-    l = ll_f_pass(f, nu, mu, x, b0, b1, b2, y, sb, sphi, n, lane, c, s);  // :85-86
+    l = ll_f_pass<WPU>(f, nu, mu, x, b0, b1, b2, y, sb, sphi, n, row0, c, s, red, w);  // :85-86
     ++r;
     if (l > hh) { ok = true; break; }                // :87
     if (phi > 0.0) pmax = phi;                       // :92-96
@@ -196,8 +217,8 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
     phi = draw(1 + r) * (pmax - pmin) + pmin;        // :100
   }
   if (ok)
-    for (int i = lane; i < n; i += 64) f[i] = f[i] * c + nu[i] * s;
-  if (lane == 0) {
+    for (int i = row0; i < n; i += 64 * WPU) f[i] = f[i] * c + nu[i] * s;
+  if (lane == 0 && (WPU == 1 || w == 0)) {
     if (a.rounds) a.rounds[u] = ok ? r : -r;
     if (a.ll) a.ll[u] = ok ? l : cur;
     if (a.counters) {
@@ -207,8 +228,14 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
   }
 }
 
+// rows per unit from which a unit gets a whole workgroup
+constexpr int WIDE_UNIT_ROWS = 1024;
+
 int launch_ess_f(hipStream_t st, const EssFArgs &a) {
-  hipLaunchKernelGGL(ess_f_kernel, dim3((a.U_pad + WPB - 1) / WPB), dim3(64 * WPB), 0, st, a);
+  if (a.Np >= WIDE_UNIT_ROWS)
+    hipLaunchKernelGGL(ess_f_kernel<4>, dim3(a.U_pad), dim3(64 * WPB), 0, st, a);
+  else
+    hipLaunchKernelGGL(ess_f_kernel<1>, dim3((a.U_pad + WPB - 1) / WPB), dim3(64 * WPB), 0, st, a);
   GP_HIP(hipGetLastError());
   return GPIRT_OK;
 }
@@ -235,12 +262,13 @@ __device__ inline void params_from_white(const double *v, const double *pm, cons
   sb[C] = INFINITY;
 }
 
+template <int WPU>
 __device__ inline double ll_param_pass(const double *__restrict__ f, const double *__restrict__ x,
                                        double b0, double b1, double b2,
                                        const int8_t *__restrict__ y, const double *sb,
-                                       const double *sphi, int n, int lane) {
+                                       const double *sphi, int n, int row0, double *red, int w) {
   double acc = 0.0;
-  for (int r = lane; r < n; r += 64) {
+  for (int r = row0; r < n; r += 64 * WPU) {
     int yy = y[r];
     if (yy > 0) {
       double xr = x[r];
@@ -248,18 +276,21 @@ __device__ inline double ll_param_pass(const double *__restrict__ f, const doubl
       acc += ordinal_cell_fast(sb[yy - 1] - gg, sb[yy] - gg, sphi);
     }
   }
-  return bcast0(wave_sum(acc));
+  return unit_sum<WPU>(acc, red, w);
 }
 
+template <int WPU>
 __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
   __shared__ double sbb[WPB][MAXC + 2];
   __shared__ double sphi[PHI_ROWS * PHI_LD];
+  __shared__ double red[WPB];
   phi_table_to_lds(sphi);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int u = blockIdx.x * WPB + w;
-  if (u >= a.U_pad || u % a.ML >= a.mloc) return;
-  double *sb = sbb[w];
+  const int u = WPU == 1 ? blockIdx.x * WPB + w : blockIdx.x;
+  if (u >= a.U_pad || u % a.ML >= a.mloc) return;    // uniform over the workgroup when WPU = 4
+  double *sb = sbb[WPU == 1 ? w : 0];
+  const int row0 = WPU == 1 ? lane : lane + 64 * w;
   const int C = a.C, n = a.Np, D = C + 2, jl = u % a.ML;
   const double *f = a.f + a.ld * u;
   const int8_t *y = a.y + a.ldy * u;
@@ -283,7 +314,8 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
   }
   double b0, b1, b2;
   params_from_white(v, pm, ps, C, b0, b1, b2, sb);
-  const double cur = ll_param_pass(f, x, b0, b1, b2, y, sb, sphi, n, lane);
+  if (WPU != 1) __syncthreads();          // the thresholds every wave just wrote (same values)
+  const double cur = ll_param_pass<WPU>(f, x, b0, b1, b2, y, sb, sphi, n, row0, red, w);
   int r = 0;
   bool ok = false;
   double l = cur;
@@ -300,7 +332,8 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
         pv[k] = rot ? v[k] * c + nv[k] * s : v[k];
       }
       params_from_white(pv, pm, ps, C, b0, b1, b2, sb);
-      l = ll_param_pass(f, x, b0, b1, b2, y, sb, sphi, n, lane);
+      if (WPU != 1) __syncthreads();
+      l = ll_param_pass<WPU>(f, x, b0, b1, b2, y, sb, sphi, n, row0, red, w);
       ++r;
       if (l > hh) { ok = true; break; }
       if (phi > 0.0) pmax = phi;
@@ -313,8 +346,9 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
     params_from_white(v, pm, ps, C, b0, b1, b2, sb);
     l = cur;
   }
+  if (WPU != 1) __syncthreads();
   const double *fin = ok ? pv : v;
-  if (lane == 0) {
+  if (lane == 0 && (WPU == 1 || w == 0)) {
 #pragma unroll
     for (int k = 0; k < MAXD; ++k) {
       if (k < 3) a.ebeta[k + 3 * u] = fin[k];
@@ -328,7 +362,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
       if (!ok) atomicAdd(&a.counters[1], 1ull);
     }
   }
-  if (lane <= C) {
+  if (lane <= C && (WPU == 1 || w == 0)) {
     double bv = sb[lane];
     a.bthr[lane + (int64_t)(C + 1) * u] = bv;
     a.bthrS[u + (int64_t)a.U_pad * lane] = bv;
@@ -336,7 +370,10 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
 }
 
 int launch_ess_param(hipStream_t st, const EssParamArgs &a) {
-  hipLaunchKernelGGL(ess_param_kernel, dim3((a.U_pad + WPB - 1) / WPB), dim3(64 * WPB), 0, st, a);
+  if (a.Np >= WIDE_UNIT_ROWS)
+    hipLaunchKernelGGL(ess_param_kernel<4>, dim3(a.U_pad), dim3(64 * WPB), 0, st, a);
+  else
+    hipLaunchKernelGGL(ess_param_kernel<1>, dim3((a.U_pad + WPB - 1) / WPB), dim3(64 * WPB), 0, st, a);
   GP_HIP(hipGetLastError());
   return GPIRT_OK;
 }

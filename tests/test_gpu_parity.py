@@ -108,7 +108,7 @@ def test_ordinal_loglik_all_missing(K):
     assert lu[0] == 0 and np.all(lr == 0)
 
 
-@pytest.mark.parametrize("C,n", [(2, 100), (5, 1000)])
+@pytest.mark.parametrize("C,n", [(2, 100), (5, 1000), (3, 2100)])   # 2100 rows: workgroup-per-unit path
 def test_ess_f_injected_streams(K, O, C, n):
     """Same f, nu, uniforms => identical accept/shrink decisions and the same new f."""
     rng = np.random.default_rng(C * n)
@@ -183,6 +183,24 @@ def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const):
         assert np.abs(sg["threshold"][fin] - sc["threshold"][fin]).max() < 1e-5
     dg, dc = g.diagnostics(), c.diagnostics()
     assert dg == dc
+    g.close(); c.close()
+
+
+def test_sweep_matches_oracle_wide_units():
+    """n >= 1024 rows per unit switches the item kernels to one workgroup per unit and the
+    Cholesky to several diagonal blocks (ragged last super-block): same parity bar."""
+    from gpirt_amd.synth import generate
+    d = generate(1300, 9, 3, seed=4)
+    cfg = _abi.default_config(n=1300, m=9, H=1, C=3, seed=8)
+    g, c = _pair(cfg, d["y"], theta_init=d["theta"])
+    for sweep in range(2):
+        g.sweep(1); c.sweep(1)
+        sg, sc = g.state(), c.state()
+        for k in ("theta", "beta", "f", "fstar"):
+            assert np.abs(sg[k] - sc[k]).max() < 1e-5, (sweep, k)
+        fin = np.isfinite(sc["threshold"])
+        assert np.abs(sg["threshold"][fin] - sc["threshold"][fin]).max() < 1e-5
+    assert g.diagnostics() == c.diagnostics()
     g.close(); c.close()
 
 
