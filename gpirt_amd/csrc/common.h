@@ -165,7 +165,7 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
                  double *work, hipStream_t st2 = nullptr, hipEvent_t ev_col = nullptr,
                  hipEvent_t ev_panel = nullptr);
 // B <- S^-1 B (two blocked triangular solves) for `batch` systems sharing the layout;
-// xtmp holds SUP * nrhs_pad doubles per system.
+// xtmp holds 4 * SUP * nrhs_pad doubles per system (split-K slabs of the diagonal steps).
 int launch_potrs(hipStream_t st, const double *L, const double *inv, int n_pad, int batch,
                  double *B, int64_t ldb, int64_t strideB, int nrhs_pad, double *xtmp);
 // Kst[r + n_pad*g] = sf^2 exp(-(xs_g - x_r)^2 / (2 ls^2)), zero outside r<n, g<G.

@@ -401,6 +401,19 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
   return GPIRT_OK;
 }
 
+// out[r + ldo*j] = sum over slabs of x[slab][r + ldx*j], two rows per thread
+__global__ void sum_slabs_kernel(const double *__restrict__ x, int nslab, int64_t slab_stride, int rows,
+                                 int64_t ldx, double *__restrict__ out, int64_t ldo) {
+  const int r = 2 * (blockIdx.x * blockDim.x + threadIdx.x), j = blockIdx.y;
+  if (r >= rows) return;
+  double2 acc = *reinterpret_cast<const double2 *>(x + r + ldx * j);
+  for (int q = 1; q < nslab; ++q) {
+    const double2 v = *reinterpret_cast<const double2 *>(x + slab_stride * q + r + ldx * j);
+    acc.x += v.x; acc.y += v.y;
+  }
+  *reinterpret_cast<double2 *>(out + r + ldo * j) = acc;
+}
+
 // Two blocked triangular solves, SUP rows per step: the diagonal step is a product with the
 // inverted super-block (written to xtmp, then copied back over B's rows), followed by one
 // rank-SUP update of the remaining rows.
@@ -410,6 +423,25 @@ int launch_potrs(hipStream_t st, const double *L, const double *inv, int n_pad, 
   const int64_t sS = (int64_t)n_pad * n_pad, sI = inv_group_elems(n_pad);
   const int64_t sX = (int64_t)SUP * nrhs_pad;
   auto diag_step = [&](int c, int bs, bool transposed) -> int {
+    if (batch == 1 && bs > TILE) {
+      // split-K: the product with the inverted super-block is only bs/128 x nrhs/128 tiles of
+      // depth bs -- too few and too deep to fill the chip -- so each 128-deep slice of K goes
+      // to its own slab of xtmp (the GEMM's batch index) and a small kernel sums the slabs
+      // back over B's rows
+      const int nsl = bs / TILE;
+      GemmArgs d{};
+      d.A = inv + (int64_t)c * SUP * SUP; d.lda = SUP;
+      d.strideA = transposed ? (int64_t)TILE : (int64_t)TILE * SUP;
+      d.B = B + (int64_t)c * SUP; d.ldb = ldb; d.strideB = TILE;
+      d.C = xtmp; d.ldc = SUP; d.strideC = sX;
+      d.M = bs; d.N = nrhs_pad; d.K = TILE; d.batch = nsl; d.alpha = 1.0; d.beta = 0.0;
+      GP_TRY(launch_gemm(st, transposed, false, d));
+      dim3 grid((bs / 2 + 255) / 256, nrhs_pad);
+      hipLaunchKernelGGL(sum_slabs_kernel, grid, dim3(256), 0, st, xtmp, nsl, sX, bs, (int64_t)SUP,
+                         B + (int64_t)c * SUP, ldb);
+      GP_HIP(hipGetLastError());
+      return GPIRT_OK;
+    }
     GemmArgs d{};
     d.A = inv + (int64_t)c * SUP * SUP; d.lda = SUP; d.strideA = sI;
     d.B = B + (int64_t)c * SUP; d.ldb = ldb; d.strideB = strideB;

@@ -253,7 +253,7 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   A_(s->d_S, (size_t)Np_pad * Np_pad * P);
   A_(s->d_inv, (size_t)inv_group_elems(Np_pad) * P);
   A_(s->d_fwork, (size_t)potrf_work_elems(Np_pad, P));
-  A_(s->d_xtmp, (size_t)SUP * G_pad * P);
+  A_(s->d_xtmp, (size_t)4 * SUP * G_pad * P);
   A_(s->d_W, (size_t)Np_pad * G_pad * P);
   A_(s->d_Gt, (size_t)U_pad * G_pad);
   A_(s->d_ebeta, 3 * (size_t)U_pad);
@@ -761,7 +761,7 @@ int gpirt_potrs(const double *L, const double *B, int32_t n, int32_t k, double *
   DevBuf dS, dI, dB, dX;
   GP_TRY(factor_from_host_L(L, n, np, dS, dI));
   GP_TRY(dB.alloc(sizeof(double) * (size_t)np * kp));
-  GP_TRY(dX.alloc(sizeof(double) * (size_t)SUP * kp));
+  GP_TRY(dX.alloc(sizeof(double) * (size_t)4 * SUP * kp));
   GP_TRY(upload_padded(B, n, k, dB.as<double>(), np, 0));
   GP_TRY(launch_potrs(0, dS.as<double>(), dI.as<double>(), np, 1, dB.as<double>(), np, 0, kp,
                       dX.as<double>()));
@@ -839,7 +839,7 @@ int gpirt_fstar_predict(const double *x, const double *L, const double *f, int32
   const int np = (int)pad_up(n), up = (int)pad_up(u), gp = (int)pad_up(n_grid);
   DevBuf dS, dI, dx, dW, dF, dGt, dout, dX;
   GP_TRY(factor_from_host_L(L, n, np, dS, dI));
-  GP_TRY(dX.alloc(sizeof(double) * (size_t)SUP * gp));
+  GP_TRY(dX.alloc(sizeof(double) * (size_t)4 * SUP * gp));
   GP_TRY(dx.alloc(sizeof(double) * n));
   GP_TRY(dW.alloc(sizeof(double) * (size_t)np * gp));
   GP_TRY(dF.alloc(sizeof(double) * (size_t)np * up));
