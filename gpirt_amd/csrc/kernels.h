@@ -65,6 +65,7 @@ struct ThetaArgs {
   const int8_t *yT;         // [ML*H, n] responses, respondent-major
   int n, H, C, mloc, ML, U_pad, G, constant_irf, R;
   double grid_lo, grid_step;
+  double os2;               // prior variance of the static step (theta_os^2, 1 when theta_os = 0)
   uint64_t seed; uint32_t sweep;
   int32_t *remaining;       // device counter
   unsigned long long *counters;  // [1] capped
@@ -72,6 +73,12 @@ struct ThetaArgs {
 int launch_theta_prepare(hipStream_t st, const ThetaArgs &a);
 int launch_theta_eval(hipStream_t st, const ThetaArgs &a, int initial);
 int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int round);
+// static (grid) respondent step, H = 1: one-hot coding of y (k = jl + ML*(y-1), ld = C*ML),
+// the per-sweep table of log cell probabilities T[G_pad, C*ML], and the inverse-CDF draw
+// from lp = T * onehot (+ prior)
+int launch_grid_onehot(hipStream_t st, const int8_t *yT, int n, int mloc, int ML, int C, double *oh);
+int launch_grid_table(hipStream_t st, const ThetaArgs &a, int G_pad, double *T);
+int launch_grid_pick(hipStream_t st, const ThetaArgs &a, const double *lp, int G_pad);
 // f[r + ld*u] = Gt[u + U_pad * idx(x_p[r])]   (main.m:69-73)
 int launch_snap(hipStream_t st, const double *Gt, int U_pad, const double *x, int64_t x_stride,
                 int Np, int P, int mloc, int ML, int G, double lo, double step, double *f,

@@ -102,6 +102,7 @@ struct gpirt_sampler {
   double *d_ebeta, *d_delta, *d_beta, *d_bthr, *d_betaS, *d_bthrS, *d_bpm, *d_bps;
   double *d_xc, *d_tnu, *d_prop, *d_hh, *d_phi, *d_pmin, *d_pmax, *d_buf, *d_Lt, *d_tpm, *d_tps;
   double *d_llu;
+  double *d_onehot, *d_T, *d_lp;   // static (grid) respondent step only
   int32_t *d_done, *d_info, *d_remaining;
   unsigned long long *d_counters;  // [3][2]: f, param, theta x (evaluations, capped)
   int64_t theta_rounds;
@@ -119,7 +120,7 @@ static void sampler_free(gpirt_sampler *s) {
                   s->d_Gt, s->d_ebeta, s->d_delta, s->d_beta, s->d_bthr, s->d_betaS, s->d_bthrS,
                   s->d_bpm, s->d_bps, s->d_xc, s->d_tnu, s->d_prop, s->d_hh, s->d_phi, s->d_pmin,
                   s->d_pmax, s->d_buf, s->d_Lt, s->d_tpm, s->d_tps, s->d_llu, s->d_done, s->d_info,
-                  s->d_remaining, s->d_counters};
+                  s->d_remaining, s->d_counters, s->d_onehot, s->d_T, s->d_lp};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
   if (s->ev_col) (void)hipEventDestroy(s->ev_col);
@@ -161,8 +162,12 @@ static int check_cfg(const gpirt_config *cfg) {
     set_error("bad grid / kernel hyper-parameters");
     return GPIRT_ERR_BAD_ARG;
   }
-  if (cfg->theta_mode != GPIRT_THETA_ESS) {
-    set_error("theta_mode %d is not available on the device yet (only GPIRT_THETA_ESS)", cfg->theta_mode);
+  if (cfg->theta_mode != GPIRT_THETA_ESS && cfg->theta_mode != GPIRT_THETA_GRID) {
+    set_error("unknown theta_mode %d", cfg->theta_mode);
+    return GPIRT_ERR_BAD_ARG;
+  }
+  if (cfg->theta_mode == GPIRT_THETA_GRID && cfg->H != 1) {
+    set_error("GPIRT_THETA_GRID is the static respondent step: H must be 1 (got %d)", cfg->H);
     return GPIRT_ERR_BAD_ARG;
   }
   if (cfg->world > 1 && !cfg->allreduce) {
@@ -231,7 +236,7 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   s->seed = cfg->seed + 0x9E3779B97F4A7C15ull * (uint64_t)cfg->chain;
   s->jitter_now = cfg->jitter;
   s->fixed_thr = thresholds != nullptr;
-  const int n = s->n, m = s->m, H = s->H, C = s->C, P = s->P, Np = s->Np, Np_pad = s->Np_pad,
+  const int n = s->n, m = s->m, H = s->H, C = s->C, P = s->P, Np_pad = s->Np_pad,
             mloc = s->mloc, ML = s->ML, U_pad = s->U_pad, G_pad = s->G_pad;
   int rc = GPIRT_OK;
   auto fail = [&](int code) { sampler_free(s); return code; };
@@ -273,6 +278,11 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   A_(s->d_llu, U_pad);
   A_(s->d_done, n); A_(s->d_info, 1); A_(s->d_remaining, 1);
   A_(s->d_counters, 6);
+  if (cfg->theta_mode == GPIRT_THETA_GRID) {
+    A_(s->d_onehot, (size_t)C * ML * Np_pad);
+    A_(s->d_T, (size_t)G_pad * C * ML);
+    A_(s->d_lp, (size_t)G_pad * Np_pad);
+  }
 #undef A_
 
   // ---- host staging -------------------------------------------------------------------
@@ -335,6 +345,10 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   UP_(s->d_betaS, hbetaS); UP_(s->d_bthrS, hbS); UP_(s->d_Lt, hLt); UP_(s->d_tpm, htpm);
   UP_(s->d_tps, htps);
 #undef UP_
+  if (cfg->theta_mode == GPIRT_THETA_GRID) {
+    if ((rc = launch_grid_onehot(s->st, s->d_yT, n, mloc, ML, C, s->d_onehot))) return fail(rc);
+    if (hipStreamSynchronize(s->st) != hipSuccess) { set_error("one-hot coding failed"); return fail(GPIRT_ERR_HIP); }
+  }
   *out = s;
   return GPIRT_OK;
 }
@@ -454,14 +468,16 @@ static ThetaArgs theta_args(gpirt_sampler *s) {
   a.R = s->cfg.max_ess_rounds; a.grid_lo = s->cfg.grid_lo; a.grid_step = s->cfg.grid_step;
   a.seed = s->seed; a.sweep = s->sweep; a.remaining = s->d_remaining;
   a.counters = s->d_counters + 4;
+  a.os2 = s->cfg.theta_os > 0 ? s->cfg.theta_os * s->cfg.theta_os : 1.0;
   return a;
 }
 
 // sum the per-respondent partial log-likelihoods over the ranks that share the chain
-static int exchange(gpirt_sampler *s) {
+static int exchange(gpirt_sampler *s, double *buf = nullptr, int64_t count = 0) {
   if (s->cfg.world <= 1) return GPIRT_OK;
   GP_HIP(hipStreamSynchronize(s->st));
-  if (s->cfg.allreduce(s->d_buf, s->n, s->cfg.allreduce_user)) {
+  if (!buf) { buf = s->d_buf; count = s->n; }
+  if (s->cfg.allreduce(buf, count, s->cfg.allreduce_user)) {
     set_error("allreduce hook failed");
     return GPIRT_ERR_COMM;
   }
@@ -491,6 +507,23 @@ static int phase_theta(gpirt_sampler *s) {
   return GPIRT_OK;
 }
 
+// static respondent step (utils/sample_score.m:1-20): table, lp = T * onehot, draw
+static int phase_theta_grid(gpirt_sampler *s) {
+  GP_TRY(mark(s, PH_THETA));
+  ThetaArgs a = theta_args(s);
+  GP_TRY(launch_grid_table(s->st, a, s->G_pad, s->d_T));
+  GemmArgs g{};
+  g.A = s->d_T; g.lda = s->G_pad;
+  g.B = s->d_onehot; g.ldb = (int64_t)s->C * s->ML;
+  g.C = s->d_lp; g.ldc = s->G_pad;
+  g.M = s->G_pad; g.N = s->Np_pad; g.K = s->C * s->ML; g.batch = 1; g.alpha = 1.0; g.beta = 0.0;
+  GP_TRY(launch_gemm(s->st, false, false, g));
+  GP_TRY(exchange(s, s->d_lp, (int64_t)s->G_pad * s->n));
+  s->theta_rounds++;
+  GP_TRY(launch_grid_pick(s->st, a, s->d_lp, s->G_pad));
+  return GPIRT_OK;
+}
+
 static int phase_snap(gpirt_sampler *s) {
   GP_TRY(mark(s, PH_SNAP));
   GP_TRY(launch_snap(s->st, s->d_Gt, s->U_pad, s->d_theta, s->Np, s->Np, s->P, s->mloc, s->ML, s->G,
@@ -508,7 +541,7 @@ int gpirt_sampler_sweep(gpirt_sampler *s, int32_t sweeps) {
     GP_TRY(phase_f(s));        // main.m:50-52
     GP_TRY(phase_param(s));
     GP_TRY(phase_fstar(s));    // main.m:55-60
-    GP_TRY(phase_theta(s));    // main.m:63
+    GP_TRY(s->cfg.theta_mode == GPIRT_THETA_GRID ? phase_theta_grid(s) : phase_theta(s));   // main.m:63
     GP_TRY(phase_snap(s));     // main.m:69-73
     GP_TRY(mark(s, -1));
     s->sweep++;

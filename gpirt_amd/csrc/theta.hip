@@ -132,6 +132,100 @@ int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int round) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Static respondent step: inverse-CDF draw on the grid (utils/sample_score.m:4-19), H = 1.
+//   lp[g,i] = sum_j log P(y_ij | f*_j(x_g))                 (sample_score.m:6-8)
+// has only G*m*C distinct cells, so they are tabulated once per sweep (T) and the sum over a
+// respondent's items becomes T times the one-hot coding of y -- an FP64 GEMM on the matrix
+// cores, G x (C*ML) x n.  The one-hot matrix never changes and is built at set-up.
+// ---------------------------------------------------------------------------------------
+__global__ void grid_onehot_kernel(const int8_t *__restrict__ yT, int n, int mloc, int ML, int C,
+                                   double *__restrict__ oh) {
+  const int jl = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (jl >= mloc || i >= n) return;
+  const int v = yT[(int64_t)ML * i + jl];
+  if (v > 0 && v <= C) oh[jl + (int64_t)ML * (v - 1) + (int64_t)ML * C * i] = 1.0;
+}
+
+int launch_grid_onehot(hipStream_t st, const int8_t *yT, int n, int mloc, int ML, int C, double *oh) {
+  hipLaunchKernelGGL(grid_onehot_kernel, dim3((mloc + 255) / 256, n), dim3(256), 0, st, yT, n, mloc, ML,
+                     C, oh);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// T[g + G_pad*(jl + ML*c)] = log-probability of category c+1 for item jl at grid point g
+__global__ __launch_bounds__(256) void grid_table_kernel(ThetaArgs a, int G_pad, double *__restrict__ T) {
+  __shared__ double sphi[PHI_ROWS * PHI_LD];
+  phi_table_to_lds(sphi);
+  __syncthreads();
+  const int g = blockIdx.x * blockDim.x + threadIdx.x, jl = blockIdx.y;
+  if (g >= a.G) return;
+  const int U_pad = a.U_pad;
+  const double xg = a.grid_lo + a.grid_step * g;
+  const double gg = a.Gt[jl + (int64_t)U_pad * g] + a.betaS[jl] + a.betaS[jl + U_pad] * xg +
+                    a.betaS[jl + 2 * (int64_t)U_pad] * xg * xg;
+  double lo = a.bthrS[jl];
+  for (int c = 0; c < a.C; ++c) {
+    const double hi = a.bthrS[jl + (int64_t)U_pad * (c + 1)];
+    T[g + (int64_t)G_pad * (jl + (int64_t)a.ML * c)] = ordinal_cell_fast(lo - gg, hi - gg, sphi);
+    lo = hi;
+  }
+}
+
+int launch_grid_table(hipStream_t st, const ThetaArgs &a, int G_pad, double *T) {
+  hipLaunchKernelGGL(grid_table_kernel, dim3((a.G + 255) / 256, a.mloc), dim3(256), 0, st, a, G_pad, T);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// one wave per respondent: add the prior (sample_score.m:7), cumulate exp(lp) (:10-11), take
+// the first grid point whose normalised cumulative sum exceeds the uniform draw (:13-18)
+__global__ __launch_bounds__(256) void grid_pick_kernel(ThetaArgs a, const double *__restrict__ lp,
+                                                        int G_pad) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + w;
+  if (i >= a.n) return;
+  const int G = a.G, chunk = (G + 63) / 64, g0 = lane * chunk, g1 = min(G, g0 + chunk);
+  const double *l = lp + (int64_t)G_pad * i;
+  const double s0 = a.tps[2 * i], s1 = a.tps[2 * i + 1];
+  const double pv = a.os2 + s0 * s0 + s1 * s1, pm = a.tpm[2 * i] + a.tpm[2 * i + 1];
+  auto val = [&](int g) {
+    const double xg = a.grid_lo + a.grid_step * g - pm;
+    return l[g] + -0.5 * xg * xg / pv;
+  };
+  double mx = -INFINITY;
+  for (int g = g0; g < g1; ++g) mx = fmax(mx, val(g));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+  double mine = 0.0;
+  for (int g = g0; g < g1; ++g) mine += exp(val(g) - mx);
+  double incl = mine;                       // inclusive scan over the lanes
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  const double total = __shfl(incl, 63, 64);
+  const double c0 = exp(val(0) - mx), span = total - c0;
+  const double r = rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, 0);
+  double c = incl - mine;
+  int first = G - 1;
+  for (int g = g0; g < g1; ++g) {
+    c += exp(val(g) - mx);
+    if ((c - c0) / span > r) { first = g; break; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off, 64));
+  if (lane == 0) a.theta[i] = a.grid_lo + a.grid_step * first;
+}
+
+int launch_grid_pick(hipStream_t st, const ThetaArgs &a, const double *lp, int G_pad) {
+  hipLaunchKernelGGL(grid_pick_kernel, dim3((a.n + 3) / 4), dim3(256), 0, st, a, lp, G_pad);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // snap: re-anchor f at the new theta from f* (main.m:69-73).  Gt is unit-contiguous, f is
 // row-contiguous: a 64x64 tile goes through LDS so that both sides are coalesced.
 // ---------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, grid):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,13 +33,14 @@ def _worker(rank, world, port, out_dir):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     d = load_fixture("Wiener_C_5")
-    y, theta = d["y"][:, :, :3], d["theta"][:, :3]
+    y, theta = _case(d, grid)
     n, m, H = y.shape
     j0, j1 = item_range(m, rank, world)
     hook = torch_allreduce(device_buffers=True, via_host=True)
     cb = _abi.ALLREDUCE_FN(lambda ptr, count, user: hook(ptr, count))
     cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=11, theta_ls=1.5, item_begin=j0, item_end=j1,
-                              rank=rank, world=world)
+                              rank=rank, world=world,
+                              theta_mode=_abi.THETA_GRID if grid else _abi.THETA_ESS)
     cfg.allreduce = cb
     s = Sampler(cfg, y, theta_init=theta)
     s.sweep(3)
@@ -50,17 +51,25 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_unsharded_device_chain(tmp_path):
+def _case(d, grid):
+    """dynamic case: 3 periods; static (grid-mode) case: the first period only"""
+    k = 1 if grid else 3
+    return d["y"][:, :, :k], d["theta"][:, :k]
+
+
+@pytest.mark.parametrize("grid", [0, 1])
+def test_two_ranks_on_one_gpu_match_unsharded_device_chain(tmp_path, grid):
     import torch.multiprocessing as mp
     from gpirt_amd import _abi
     from gpirt_amd.sampler import Sampler
     from conftest import load_fixture
 
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), grid), nprocs=2, join=True)
     d = load_fixture("Wiener_C_5")
-    y, theta = d["y"][:, :, :3], d["theta"][:, :3]
+    y, theta = _case(d, grid)
     n, m, H = y.shape
-    cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=11, theta_ls=1.5)
+    cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=11, theta_ls=1.5,
+                              theta_mode=_abi.THETA_GRID if grid else _abi.THETA_ESS)
     ref = Sampler(cfg, y, theta_init=theta)
     ref.sweep(3)
     full = ref.state()

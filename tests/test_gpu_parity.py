@@ -204,6 +204,36 @@ def test_sweep_matches_oracle_wide_units():
     g.close(); c.close()
 
 
+def test_grid_mode_respondent_step_matches_oracle():
+    """Static respondent step (utils/sample_score.m:1-20) on the device: table + one-hot GEMM +
+    inverse-CDF draw against the oracle's triple loop, with missing cells.  theta lives on the
+    grid, so agreement is exact up to the rounding of lo + step*k."""
+    from gpirt_amd.synth import generate
+    for n, m, C, seed in ((300, 21, 5, 3), (150, 7, 2, 9)):
+        d = generate(n, m, C, seed=seed)
+        y = d["y"].copy()
+        rng = np.random.default_rng(seed)
+        y[rng.random(y.shape) < 0.15] = 0
+        cfg = _abi.default_config(n=n, m=m, H=1, C=C, seed=seed, theta_mode=_abi.THETA_GRID)
+        g, c = _pair(cfg, y, theta_init=d["theta"])
+        for sweep in range(3):
+            g.sweep(1); c.sweep(1)
+            sg, sc = g.state(), c.state()
+            assert np.abs(sg["theta"] - sc["theta"]).max() < 1e-12, sweep
+            for k in ("beta", "f", "fstar"):
+                assert np.abs(sg[k] - sc[k]).max() < 1e-5, (sweep, k)
+        assert g.diagnostics() == c.diagnostics()
+        g.close(); c.close()
+
+
+def test_grid_mode_rejects_dynamic_theta():
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd._lib import GpirtError
+    cfg = _abi.default_config(n=20, m=3, H=2, C=2, theta_mode=_abi.THETA_GRID)
+    with pytest.raises(GpirtError):
+        Sampler(cfg, np.ones((20, 3, 2), dtype=np.int8))
+
+
 def test_gpirtmcmc_drop_in_recovers_theta():
     """The reference's own acceptance metric (gpirt-sythetic.R:257-260,275) on its own
     fixture, through the gpirtMCMC mirror; and the GPU chain agrees with the CPU chain."""
