@@ -13,6 +13,7 @@ namespace gpirt {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;        // k-slab depth held in LDS
+constexpr int SMALL_GEMM_TILES = 256;   // at most this many 128x128 tiles go to the 64x64-tile kernel
 constexpr int LDS_LD = 144;   // 128 + 16: the four k-rows one ds_read_b64 touches land on
                               // disjoint bank halves
 
@@ -180,6 +181,108 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
       }
 }
 
+// ---------------------------------------------------------------------------------------
+// Low-latency variant for products with few tiles (the panel solves and in-panel updates on
+// the Cholesky's critical path, K = 128): a 128x128 tile per workgroup leaves most CUs idle
+// and makes each workgroup grind through the whole depth alone.  Here a workgroup owns a
+// 64x64 tile (four waves x 2x2 MFMA tiles), K advances in chunks of 64 held whole in LDS, and
+// the next chunk's global loads are in flight during the current chunk's matrix work.
+// ---------------------------------------------------------------------------------------
+constexpr int SK = 64;       // chunk depth
+constexpr int SLD = 80;      // 64 + 16: same bank argument as LDS_LD
+
+template <bool KCONTIG>
+__device__ __forceinline__ double2 chunk_ld(const double *__restrict__ base, int64_t ld, int row0,
+                                            int k0, int tid, int p) {
+  if (!KCONTIG)
+    return *reinterpret_cast<const double2 *>(base + (row0 + ((tid & 31) << 1)) +
+                                              ld * (int64_t)(k0 + (tid >> 5) + 8 * p));
+  return *reinterpret_cast<const double2 *>(base + (k0 + ((tid & 31) << 1)) +
+                                            ld * (int64_t)(row0 + (tid >> 5) + 8 * p));
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void chunk_st(double (*s)[SLD], int tid, int p, double2 v) {
+  if (!KCONTIG) {
+    *reinterpret_cast<double2 *>(&s[(tid >> 5) + 8 * p][(tid & 31) << 1]) = v;
+  } else {
+    s[(tid & 31) << 1][(tid >> 5) + 8 * p] = v.x;
+    s[((tid & 31) << 1) + 1][(tid >> 5) + 8 * p] = v.y;
+  }
+}
+
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs g, int nbn) {
+  __shared__ double sA[SK][SLD];
+  __shared__ double sB[SK][SLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bi = blockIdx.x / nbn, bj = blockIdx.x % nbn, z = blockIdx.y;
+  const double *__restrict__ A = g.A + g.strideA * z;
+  const double *__restrict__ B = g.B + g.strideB * z;
+  double *C = g.C + g.strideC * z;   // may alias A or B
+  const int i0 = bi * 64, j0 = bj * 64;
+  const int wm0 = (wave & 1) * 32, wn0 = (wave >> 1) * 32;
+  const int lr = lane & 15, lk = lane >> 4;
+  const double alpha = g.alpha, beta = g.beta;
+  const int64_t lda = g.lda, ldb = g.ldb, ldc = g.ldc;
+
+  double2 ra[8], rb[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    ra[p] = chunk_ld<AT>(A, lda, i0, 0, tid, p);
+    rb[p] = chunk_ld<!BT>(B, ldb, j0, 0, tid, p);
+  }
+  v4d acc[2][2];
+  if (beta != 0.0) {
+    const double sc = beta / alpha;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[tj][ti][r] = sc * C[(i0 + wm0 + ti * 16 + lr) + ldc * (int64_t)(j0 + wn0 + tj * 16 + lk + 4 * r)];
+  } else {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+
+  for (int k0 = 0; k0 < g.K; k0 += SK) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      chunk_st<AT>(sA, tid, p, ra[p]);
+      chunk_st<!BT>(sB, tid, p, rb[p]);
+    }
+    __syncthreads();
+    if (k0 + SK < g.K) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        ra[p] = chunk_ld<AT>(A, lda, i0, k0 + SK, tid, p);
+        rb[p] = chunk_ld<!BT>(B, ldb, j0, k0 + SK, tid, p);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < SK / 4; ++kk) {
+      const double fa0 = sB[kk * 4 + lk][wn0 + lr], fa1 = sB[kk * 4 + lk][wn0 + 16 + lr];
+      const double fb0 = sA[kk * 4 + lk][wm0 + lr], fb1 = sA[kk * 4 + lk][wm0 + 16 + lr];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0, fb0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0, fb1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1, fb0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1, fb1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        C[(i0 + wm0 + ti * 16 + lr) + ldc * (int64_t)(j0 + wn0 + tj * 16 + lk + 4 * r)] = alpha * acc[tj][ti][r];
+}
+
 template <bool AT, bool BT>
 static int launch_gemm_mode(hipStream_t st, const GemmArgs &a, int mode, dim3 grid, int nbm, int nbn) {
   dim3 block(256);
@@ -206,6 +309,17 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
   if (mode == 4) {   // whole 8x4 super-tiles, a multiple of 8 of them (one share per XCD)
     int64_t nsup = (int64_t)((nbm + 7) / 8) * ((nbn + 3) / 4);
     tiles = (nsup + 7) / 8 * 8 * 32;
+  }
+  // few tiles and a depth that is a multiple of the chunk: the low-latency 64x64 variant
+  static const bool no_small = getenv("GPIRT_NO_SMALL_GEMM") != nullptr;
+  if (mode == 0 && !no_small && tiles * a.batch <= SMALL_GEMM_TILES && a.K % SK == 0 && a.K <= 512) {
+    dim3 sgrid((unsigned)(4 * tiles), (unsigned)a.batch), block(256);
+    if (!AT && BT) hipLaunchKernelGGL((gemm_small_kernel<false, true>), sgrid, block, 0, st, a, 2 * nbn);
+    else if (!AT && !BT) hipLaunchKernelGGL((gemm_small_kernel<false, false>), sgrid, block, 0, st, a, 2 * nbn);
+    else if (AT && !BT) hipLaunchKernelGGL((gemm_small_kernel<true, false>), sgrid, block, 0, st, a, 2 * nbn);
+    else { set_error("launch_gemm: A^T B^T is not built"); return GPIRT_ERR_BAD_ARG; }
+    GP_HIP(hipGetLastError());
+    return GPIRT_OK;
   }
   dim3 grid((unsigned)tiles, (unsigned)a.batch);
   // only the combinations the sweep uses are instantiated
