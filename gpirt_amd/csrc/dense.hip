@@ -37,14 +37,27 @@ __device__ __forceinline__ double2 slab_ld(const double *__restrict__ base, int6
                                             ld * (int64_t)(row0 + (tid >> 3) + 32 * p));
 }
 
+// LDS image of one operand slab.  An operand whose tile index is contiguous in memory is kept
+// k-major, [k][index] with row stride LDS_LD; an operand whose K index is contiguous is kept
+// index-major, [index][k] with row stride KLD, so that its staging stores stay 16-byte vector
+// stores instead of transposing scalar stores (which collided 8-way on the banks).  KLD = 20:
+// the 16 index rows of one fragment read start 40 dwords apart, which tiles the 64 banks
+// exactly twice.
+constexpr int KLD = 20;
+template <bool KCONTIG> struct SlabImage { static constexpr int SIZE = KCONTIG ? TILE * KLD : BK * LDS_LD; };
+
 template <bool KCONTIG>
-__device__ __forceinline__ void slab_st(double (*s)[LDS_LD], int tid, int p, double2 v) {
-  if (!KCONTIG) {
-    *reinterpret_cast<double2 *>(&s[(tid >> 6) + 4 * p][(tid & 63) << 1]) = v;
-  } else {
-    s[(tid & 7) << 1][(tid >> 3) + 32 * p] = v.x;
-    s[((tid & 7) << 1) + 1][(tid >> 3) + 32 * p] = v.y;
-  }
+__device__ __forceinline__ void slab_st(double *s, int tid, int p, double2 v) {
+  if (!KCONTIG)
+    *reinterpret_cast<double2 *>(&s[((tid >> 6) + 4 * p) * LDS_LD + ((tid & 63) << 1)]) = v;
+  else
+    *reinterpret_cast<double2 *>(&s[((tid >> 3) + 32 * p) * KLD + ((tid & 7) << 1)]) = v;
+}
+
+// element (k, idx) of a slab image
+template <bool KCONTIG>
+__device__ __forceinline__ double slab_at(const double *s, int k, int idx) {
+  return KCONTIG ? s[idx * KLD + k] : s[k * LDS_LD + idx];
 }
 
 #define TILE_LOAD(KC, base, ld, row0, k0, r)          \
@@ -63,8 +76,9 @@ __device__ __forceinline__ void slab_st(double (*s)[LDS_LD], int tid, int p, dou
 // a name of its own for the once-per-sweep nu = L*Z launch (so that a profile lists it apart).
 template <bool AT, bool BT, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, int nbn) {
-  __shared__ double sA[2][BK][LDS_LD];
-  __shared__ double sB[2][BK][LDS_LD];
+  constexpr bool AK = AT, BKC = !BT;   // is the K index the contiguous one?
+  __shared__ __attribute__((aligned(16))) double sA[2][SlabImage<AK>::SIZE];
+  __shared__ __attribute__((aligned(16))) double sB[2][SlabImage<BKC>::SIZE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int t = blockIdx.x, bi, bj;
   if (MODE == 1) {
@@ -131,28 +145,41 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
 
   const int klast = kend - BK;
   int buf = 0;
+  // fragments of k-step kk+1 are read while the 16 MFMAs of k-step kk issue
+  double fa[2][4], fb[2][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    fa[0][q] = slab_at<BKC>(sB[0], lk, wn0 + q * 16 + lr);  // MFMA row index  = j
+    fb[0][q] = slab_at<AK>(sA[0], lk, wm0 + q * 16 + lr);   // MFMA col index  = i
+  }
   // single-block loop body: the prefetch of the slab after the last one re-reads the last
   // slab (clamped index) and its LDS store lands in the idle buffer
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const int kn = min(k0 + BK, klast);
     TILE_LOAD(AT, A, lda, i0, kn, ra);
     TILE_LOAD(!BT, B, ldb, j0, kn, rb);
-    // fragments of k-step kk+1 are read while the 16 MFMAs of k-step kk issue
-    double fa[2][4], fb[2][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      fa[0][q] = sB[buf][lk][wn0 + q * 16 + lr];  // MFMA row index  = j
-      fb[0][q] = sA[buf][lk][wm0 + q * 16 + lr];  // MFMA col index  = i
-    }
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
       if (kk + 1 < BK / 4) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          fa[(kk + 1) & 1][q] = sB[buf][(kk + 1) * 4 + lk][wn0 + q * 16 + lr];
-          fb[(kk + 1) & 1][q] = sA[buf][(kk + 1) * 4 + lk][wm0 + q * 16 + lr];
+          fa[(kk + 1) & 1][q] = slab_at<BKC>(sB[buf], (kk + 1) * 4 + lk, wn0 + q * 16 + lr);
+          fb[(kk + 1) & 1][q] = slab_at<AK>(sA[buf], (kk + 1) * 4 + lk, wm0 + q * 16 + lr);
+        }
+      } else {
+        // the slab's last k-step has its fragments in registers already: stage the next
+        // slab, pass the barrier and read the next slab's first fragments BEFORE issuing
+        // the last 16 MFMAs, so that the barrier and the LDS latency hide under them
+        TILE_STORE(AT, sA[buf ^ 1], ra);
+        TILE_STORE(!BT, sB[buf ^ 1], rb);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          fa[0][q] = slab_at<BKC>(sB[buf ^ 1], lk, wn0 + q * 16 + lr);
+          fb[0][q] = slab_at<AK>(sA[buf ^ 1], lk, wm0 + q * 16 + lr);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);   // reads first: their latency hides under the MFMAs
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
@@ -161,11 +188,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
                                                              acc[tj][ti], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the sched barriers keep the staging stores (and the wait for the global loads they
-    // need) behind the MFMAs of this slab: the loads' latency is covered by the matrix work
-    TILE_STORE(AT, sA[buf ^ 1], ra);
-    TILE_STORE(!BT, sB[buf ^ 1], rb);
-    __syncthreads();
     buf ^= 1;
   }
 
@@ -201,20 +223,27 @@ __device__ __forceinline__ double2 chunk_ld(const double *__restrict__ base, int
                                             ld * (int64_t)(row0 + (tid >> 5) + 8 * p));
 }
 
+constexpr int SKLD = 68;     // row stride of the index-major image of a K-contiguous operand
+template <bool KCONTIG> struct ChunkImage { static constexpr int SIZE = KCONTIG ? 64 * SKLD : SK * SLD; };
+
 template <bool KCONTIG>
-__device__ __forceinline__ void chunk_st(double (*s)[SLD], int tid, int p, double2 v) {
-  if (!KCONTIG) {
-    *reinterpret_cast<double2 *>(&s[(tid >> 5) + 8 * p][(tid & 31) << 1]) = v;
-  } else {
-    s[(tid & 31) << 1][(tid >> 5) + 8 * p] = v.x;
-    s[((tid & 31) << 1) + 1][(tid >> 5) + 8 * p] = v.y;
-  }
+__device__ __forceinline__ void chunk_st(double *s, int tid, int p, double2 v) {
+  if (!KCONTIG)
+    *reinterpret_cast<double2 *>(&s[((tid >> 5) + 8 * p) * SLD + ((tid & 31) << 1)]) = v;
+  else
+    *reinterpret_cast<double2 *>(&s[((tid >> 5) + 8 * p) * SKLD + ((tid & 31) << 1)]) = v;
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ double chunk_at(const double *s, int k, int idx) {
+  return KCONTIG ? s[idx * SKLD + k] : s[k * SLD + idx];
 }
 
 template <bool AT, bool BT>
 __global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs g, int nbn) {
-  __shared__ double sA[SK][SLD];
-  __shared__ double sB[SK][SLD];
+  constexpr bool AK = AT, BKC = !BT;
+  __shared__ __attribute__((aligned(16))) double sA[ChunkImage<AK>::SIZE];
+  __shared__ __attribute__((aligned(16))) double sB[ChunkImage<BKC>::SIZE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bi = blockIdx.x / nbn, bj = blockIdx.x % nbn, z = blockIdx.y;
   const double *__restrict__ A = g.A + g.strideA * z;
@@ -265,8 +294,8 @@ __global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs g, int nbn)
     }
 #pragma unroll
     for (int kk = 0; kk < SK / 4; ++kk) {
-      const double fa0 = sB[kk * 4 + lk][wn0 + lr], fa1 = sB[kk * 4 + lk][wn0 + 16 + lr];
-      const double fb0 = sA[kk * 4 + lk][wm0 + lr], fb1 = sA[kk * 4 + lk][wm0 + 16 + lr];
+      const double fa0 = chunk_at<BKC>(sB, kk * 4 + lk, wn0 + lr), fa1 = chunk_at<BKC>(sB, kk * 4 + lk, wn0 + 16 + lr);
+      const double fb0 = chunk_at<AK>(sA, kk * 4 + lk, wm0 + lr), fb1 = chunk_at<AK>(sA, kk * 4 + lk, wm0 + 16 + lr);
       acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0, fb0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0, fb1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1, fb0, acc[1][0], 0, 0, 0);
