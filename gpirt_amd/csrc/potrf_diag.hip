@@ -29,58 +29,53 @@ __device__ __forceinline__ double x_at(const double *T, const double *dinv, int 
   return r > c ? T[c * XLD + r] : (r == c ? dinv[r] : 0.0);
 }
 
-// ---- inner 32x32 block on one wave (lanes 0..31): row r of the block in registers ----------
+// ---- inner 32x32 block on one wave ----------------------------------------------------------
+// Lanes 0..31 keep the rows of the block (lane r: row r of A, becoming row r of L); lanes
+// 32..63 keep the columns of B, which starts as the identity and ends as X = L^-1 (forward
+// substitution L X = I, column-oriented).  Pivot step J of the factorisation and step J of
+// the substitution are the same arithmetic on the two halves: with the pivot column
+// uc[c] = A[c][J] (c > J, before scaling) and y = 1/sqrt(A[J][J]),
+//     x[c] -= (x[J] y^2) uc[c],   x[J] *= y
+// gives L[r][J] = a[J] y on the low half and X[J][t] = b[J] y on the high half, so the
+// inverse costs no extra instructions -- a single wave issues one instruction per ~4.5 clocks
+// whatever the lane count, and that issue rate is what bounds this loop.  The pivot column
+// travels through LDS (ucol); the next step's column is final after this step's first
+// update, so it is exchanged right then (into un[]) and its round trip overlaps the rest of
+// the step and the next 1/sqrt chain.
 template <int J>
-__device__ __forceinline__ void blk_factor_step(double (&a)[SB], double *ucol, double *dinv_p, int r,
-                                                int &bad) {
-  ucol[r] = a[J];                         // wave-local exchange: LDS ops of a wave stay in order
-  double d = ucol[J];
+__device__ __forceinline__ void blk_step(double (&x)[SB], double (&uc)[SB], double (&un)[SB],
+                                         double *ucol, double *dinv_p, int r, int half, int &bad) {
+  // the pivot comes straight out of lane J's register
+  double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x[J]), J),
+                              __builtin_amdgcn_readlane(__double2loint(x[J]), J));
   if (!(d > 0.0)) { bad = J + 1; d = 1.0; }
+  asm volatile("" : "+v"(bad));         // settle the flag now: 32 deferred conditions spilled SGPRs
   const double y = rsqrt_nr(d);
-  const double w = a[J] * (y * y);        // A[r][J] / d
-  a[J] = a[J] * y;                        // L[r][J]
-  if (r == J) dinv_p[J] = y;
-  double uc[SB];                          // all pivot-column reads in flight before the first use
+  const double w = x[J] * (y * y);        // A[r][J] / d   |   X[J][t] / L[J][J]
+  if constexpr (J + 1 < SB) {
+    x[J + 1] -= w * uc[J + 1];
+    asm volatile("" : "+v"(x[J + 1]));
+    if (!half) ucol[r] = x[J + 1];        // wave-local exchange: LDS ops of a wave stay in order
 #pragma unroll
-  for (int c = J + 1; c < SB; ++c) uc[c] = ucol[c];
+    for (int c = J + 2; c < SB; ++c) un[c] = ucol[c];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  x[J] = x[J] * y;                        // L[r][J]       |   X[J][t]
+  if (r == J && !half) dinv_p[J] = y;
 #pragma unroll
-  for (int c = J + 1; c < SB; ++c) {
-    a[c] -= w * uc[c];
+  for (int c = J + 2; c < SB; ++c) {
+    x[c] -= w * uc[c];
     // pin the update to this step: left alone, the compiler defers every update that the
     // next pivot does not need and keeps w and the pivot column of all 32 steps alive
-    asm volatile("" : "+v"(a[c]));
+    asm volatile("" : "+v"(x[c]));
   }
 }
 template <int J0, int J1>
-__device__ __forceinline__ void blk_factor_range(double (&a)[SB], double *ucol, double *dinv_p, int r,
-                                                 int &bad) {
+__device__ __forceinline__ void blk_range(double (&x)[SB], double (&uc)[SB], double (&un)[SB],
+                                          double *ucol, double *dinv_p, int r, int half, int &bad) {
   if constexpr (J0 < J1) {
-    blk_factor_step<J0>(a, ucol, dinv_p, r, bad);
-    blk_factor_range<J0 + 1, J1>(a, ucol, dinv_p, r, bad);
-  }
-}
-
-// column t of the inverse of the 32x32 factor; Tp points at the block's (0,0) entry
-template <int I>
-__device__ __forceinline__ void blk_inverse_step(double (&x)[SB], const double *Tp, const double *dinv_p,
-                                                 int t) {
-  const double *Lr = Tp + I * XLD;
-  double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-  for (int c = 0; c + 1 < I; c += 2) {
-    s0 += Lr[c] * x[c];
-    s1 += Lr[c + 1] * x[c + 1];
-  }
-  if (I & 1) s0 += Lr[I - 1] * x[I - 1];
-  x[I] = ((I == t ? 1.0 : 0.0) - (s0 + s1)) * dinv_p[I];
-  asm volatile("" : "+v"(x[I]));
-}
-template <int I0, int I1>
-__device__ __forceinline__ void blk_inverse_range(double (&x)[SB], const double *Tp,
-                                                  const double *dinv_p, int t) {
-  if constexpr (I0 < I1) {
-    blk_inverse_step<I0>(x, Tp, dinv_p, t);
-    blk_inverse_range<I0 + 1, I1>(x, Tp, dinv_p, t);
+    blk_step<J0>(x, uc, un, ucol, dinv_p, r, half, bad);
+    blk_range<J0 + 1, J1>(x, un, uc, ucol, dinv_p, r, half, bad);
   }
 }
 
@@ -122,24 +117,30 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
   for (int p = 0; p < TILE / SB; ++p) {
     const int i0 = p * SB;
     double *Tp = &T[i0 * XLD + i0];
-    if (wave == 0 && lane < SB && !(dbg & 1)) {
-      const int r = lane;
-      double a[SB];
+    if (wave == 0 && !(dbg & 1)) {
+      const int r = lane & 31, half = lane >> 5;
+      double x[SB], uc[SB], un[SB];
+      // both halves issue the same unconditional loads; the high half then swaps in the identity
 #pragma unroll
-      for (int c = 0; c < SB; ++c) a[c] = Tp[r * XLD + c];
+      for (int c = 0; c < SB; ++c) x[c] = Tp[r * XLD + c];
+#pragma unroll
+      for (int c = 0; c < SB; ++c) x[c] = half ? (c == r ? 1.0 : 0.0) : x[c];
+      if (!half) ucol[r] = x[0];
+#pragma unroll
+      for (int c = 1; c < SB; ++c) uc[c] = ucol[c];
       int bad = 0;
-      blk_factor_range<0, SB>(a, ucol, &dinv[i0], r, bad);
-      if (bad && r == 0) atomicMax(info, kb * TILE + i0 + bad);
+      blk_range<0, SB>(x, uc, un, ucol, &dinv[i0], r, half, bad);
+      if (bad && lane == 0) atomicMax(info, kb * TILE + i0 + bad);
+      // row r of the image: L[r][c] for c <= r from the low half, X[c][r] (transposed) for
+      // c > r from the high half.  Every lane stores every element, the lane that does not
+      // own it into a dump slot: 32 plain stores instead of 32 divergent branches.
+      // (the dump slot is the row's padding column of the image)
+      double *Trow = &T[(i0 + r) * XLD];
 #pragma unroll
-      for (int c = 0; c < SB; ++c) Tp[r * XLD + c] = c <= r ? a[c] : 0.0;
-      // inverse of the diagonal block: lane t owns column t
-      double x[SB];
-#pragma unroll
-      for (int c = 0; c < SB; ++c) x[c] = 0.0;
-      blk_inverse_range<0, SB>(x, Tp, &dinv[i0], r);
-#pragma unroll
-      for (int i = 1; i < SB; ++i)
-        if (i > r) Tp[r * XLD + i] = x[i];        // X[i][t] at T[t][i]
+      for (int c = 0; c < SB; ++c) {
+        const int own = ((int)(c > r) ^ half) ^ 1;            // low half: c <= r, high half: c > r
+        Trow[own ? i0 + c : TILE + half] = x[c];
+      }
     }
     __syncthreads();
 
