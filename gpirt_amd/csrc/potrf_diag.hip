@@ -9,7 +9,6 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int XLD = TILE + 2;   // row stride of the LDS image (even: pairs stay 16-byte aligned)
 constexpr int SB = 32;          // inner block size
-constexpr int MLD = 18;         // row stride of the per-wave 32x16 scratch
 
 __device__ __forceinline__ v4d mfma4(double a, double b, v4d c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -27,6 +26,12 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // (X[r][c], r > c, at T[c][r]) with its diagonal in dinv: one 133 KB image holds L and X.
 __device__ __forceinline__ double x_at(const double *T, const double *dinv, int r, int c) {
   return r > c ? T[c * XLD + r] : (r == c ? dinv[r] : 0.0);
+}
+// the same element with both loads issued unconditionally (always in bounds) and a select:
+// no divergent control flow inside the MFMA loops
+__device__ __forceinline__ double x_sel(const double *T, const double *dinv, int r, int c) {
+  const double t = T[c * XLD + r], dd = dinv[r];
+  return r > c ? t : (r == c ? dd : 0.0);
 }
 
 // ---- inner 32x32 block on one wave ----------------------------------------------------------
@@ -89,7 +94,6 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
   __shared__ __attribute__((aligned(16))) double T[TILE * XLD];
   __shared__ __attribute__((aligned(16))) double dinv[TILE];
   __shared__ __attribute__((aligned(16))) double ucol[SB];
-  __shared__ __attribute__((aligned(16))) double Ms[4][SB * MLD];
   const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double *A = S + (int64_t)n_pad * n_pad * z + (int64_t)kb * TILE * (n_pad + 1);
@@ -198,41 +202,88 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
   }
   __syncthreads();
 
-  // off-diagonal blocks of X = L^-1 by block substitution, one distance level at a time:
-  //   X_ip = -X_ii * sum_{k=p}^{i-1} L_ik X_kp
-  // A task is a 32x16 column strip of X_ip: the inner sum goes to the wave's scratch, the
-  // product with X_ii reads it back as the MFMA's second operand.
-  double *M = Ms[wave];
-  for (int dlev = 1; dlev < TILE / SB; ++dlev) {
-    const int ntask = 2 * (TILE / SB - dlev);
-    for (int task = wave; task < ((dbg & 4) ? 0 : ntask); task += 4) {
-      const int p = task >> 1, cs = task & 1, i = p + dlev;
-      const int i0 = p * SB, i1 = i * SB, c0 = i0 + 16 * cs;
+  // Off-diagonal blocks of X = L^-1 by recursive doubling: for a lower-triangular
+  // [[A,0],[B,C]] the inverse is [[A^-1,0],[-C^-1 B A^-1, C^-1]].  Level 1 fills X_10 and
+  // X_32 (32x32), level 2 the 64x64 block below the first 64 columns.  All products run on
+  // MFMA straight from the image; the inner product M = B A^-1 is parked in the (still
+  // unused) destination region of the result, transposed like the result itself.
+  if (!(dbg & 4)) {
+    // ---- level 1: wave = (pair, column strip of 16) --------------------------------------
+    {
+      const int pair = wave >> 1, cs = wave & 1;
+      const int p0 = 64 * pair, i1 = p0 + SB, c0 = p0 + 16 * cs;
       v4d m0 = {0.0, 0.0, 0.0, 0.0}, m1 = {0.0, 0.0, 0.0, 0.0};
-      for (int kk = 0; kk < (SB / 4) * dlev; ++kk) {
-        const int k = i0 + 4 * kk + lk;                      // global column of L / row of X
-        const double bv = x_at(T, dinv, k, c0 + lr);
+#pragma unroll
+      for (int kk = 0; kk < SB / 4; ++kk) {
+        if (kk < 4 * cs) continue;                       // X_pp is lower-triangular
+        const int k = p0 + 4 * kk + lk;
+        const double bv = x_sel(T, dinv, k, c0 + lr);
         m0 = mfma4(T[(i1 + lr) * XLD + k], bv, m0);
         m1 = mfma4(T[(i1 + 16 + lr) * XLD + k], bv, m1);
       }
+      double *Mt = &T[(c0 + lr) * XLD + i1];             // M[row][col = lr] at Mt[row]
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        M[(lk + 4 * g) * MLD + lr] = m0[g];
-        M[(16 + lk + 4 * g) * MLD + lr] = m1[g];
+        Mt[lk + 4 * g] = m0[g];
+        Mt[16 + lk + 4 * g] = m1[g];
       }
+      double bm[SB / 4];
+#pragma unroll
+      for (int kk = 0; kk < SB / 4; ++kk) bm[kk] = Mt[4 * kk + lk];
       v4d o0 = {0.0, 0.0, 0.0, 0.0}, o1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int kk = 0; kk < SB / 4; ++kk) {
-        const int k = 4 * kk + lk;
-        const double bv = M[k * MLD + lr];
-        o0 = mfma4(x_at(T, dinv, i1 + lr, i1 + k), bv, o0);
-        o1 = mfma4(x_at(T, dinv, i1 + 16 + lr, i1 + k), bv, o1);
+        const int k = i1 + 4 * kk + lk;
+        if (kk < 4) o0 = mfma4(x_sel(T, dinv, i1 + lr, k), bm[kk], o0);
+        o1 = mfma4(x_sel(T, dinv, i1 + 16 + lr, k), bm[kk], o1);
       }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {      // X_ip[row][col] transposed into the upper triangle
-        T[(c0 + lr) * XLD + i1 + lk + 4 * g] = -o0[g];
-        T[(c0 + lr) * XLD + i1 + 16 + lk + 4 * g] = -o1[g];
+      for (int g = 0; g < 4; ++g) {
+        Mt[lk + 4 * g] = -o0[g];
+        Mt[16 + lk + 4 * g] = -o1[g];
       }
+    }
+    __syncthreads();
+    // ---- level 2, inner product M = L_BA X_AA: wave = 16-row tile of the lower 64 rows -----
+    {
+      const int ti = wave;
+      v4d acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int k = 4 * kk + lk;
+        const double av = T[(64 + 16 * ti + lr) * XLD + k];
+#pragma unroll
+        for (int cs = 0; cs <= kk / 4; ++cs)             // X_AA[k][c] = 0 for k < c
+          acc[cs] = mfma4(av, x_sel(T, dinv, k, 16 * cs + lr), acc[cs]);
+      }
+#pragma unroll
+      for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) T[(16 * cs + lr) * XLD + 64 + 16 * ti + lk + 4 * g] = acc[cs][g];
+    }
+    __syncthreads();
+    // ---- level 2, X_BA = -X_BB M: wave = column strip of 16 (reads and writes only its own
+    // 16 image rows of the parked M) ----------------------------------------------------------
+    {
+      const int cs = wave;
+      double *Mt = &T[(16 * cs + lr) * XLD + 64];
+      double bm[16];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) bm[kk] = Mt[4 * kk + lk];
+      v4d o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int ti = kk / 4; ti < 4; ++ti)              // X_BB is lower-triangular
+          o[ti] = mfma4(x_sel(T, dinv, 64 + 16 * ti + lr, 64 + 4 * kk + lk), bm[kk], o[ti]);
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Mt[16 * ti + lk + 4 * g] = -o[ti][g];
     }
     __syncthreads();
   }
