@@ -49,7 +49,7 @@ __device__ __forceinline__ double x_sel(const double *T, const double *dinv, int
 // the step and the next 1/sqrt chain.
 template <int J>
 __device__ __forceinline__ void blk_step(double (&x)[SB], double (&uc)[SB], double (&un)[SB],
-                                         double *ucol, double *dinv_p, int r, int half, int &bad) {
+                                         double *ucol, double *dinv_p, int lane, int &bad) {
   // the pivot comes straight out of lane J's register
   double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x[J]), J),
                               __builtin_amdgcn_readlane(__double2loint(x[J]), J));
@@ -60,13 +60,14 @@ __device__ __forceinline__ void blk_step(double (&x)[SB], double (&uc)[SB], doub
   if constexpr (J + 1 < SB) {
     x[J + 1] -= w * uc[J + 1];
     asm volatile("" : "+v"(x[J + 1]));
-    if (!half) ucol[r] = x[J + 1];        // wave-local exchange: LDS ops of a wave stay in order
+    ucol[lane] = x[J + 1];                // wave-local exchange (LDS ops of a wave stay in order);
+                                          // the high half's 32 entries are never read
 #pragma unroll
     for (int c = J + 2; c < SB; ++c) un[c] = ucol[c];
     __builtin_amdgcn_sched_barrier(0);
   }
   x[J] = x[J] * y;                        // L[r][J]       |   X[J][t]
-  if (r == J && !half) dinv_p[J] = y;
+  dinv_p[J] = y;                          // every lane holds the same y: one plain store
 #pragma unroll
   for (int c = J + 2; c < SB; ++c) {
     x[c] -= w * uc[c];
@@ -77,10 +78,10 @@ __device__ __forceinline__ void blk_step(double (&x)[SB], double (&uc)[SB], doub
 }
 template <int J0, int J1>
 __device__ __forceinline__ void blk_range(double (&x)[SB], double (&uc)[SB], double (&un)[SB],
-                                          double *ucol, double *dinv_p, int r, int half, int &bad) {
+                                          double *ucol, double *dinv_p, int lane, int &bad) {
   if constexpr (J0 < J1) {
-    blk_step<J0>(x, uc, un, ucol, dinv_p, r, half, bad);
-    blk_range<J0 + 1, J1>(x, un, uc, ucol, dinv_p, r, half, bad);
+    blk_step<J0>(x, uc, un, ucol, dinv_p, lane, bad);
+    blk_range<J0 + 1, J1>(x, un, uc, ucol, dinv_p, lane, bad);
   }
 }
 
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
                                                         int *__restrict__ info, int dbg) {
   __shared__ __attribute__((aligned(16))) double T[TILE * XLD];
   __shared__ __attribute__((aligned(16))) double dinv[TILE];
-  __shared__ __attribute__((aligned(16))) double ucol[SB];
+  __shared__ __attribute__((aligned(16))) double ucol[2 * SB];
   const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double *A = S + (int64_t)n_pad * n_pad * z + (int64_t)kb * TILE * (n_pad + 1);
@@ -129,11 +130,11 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
       for (int c = 0; c < SB; ++c) x[c] = Tp[r * XLD + c];
 #pragma unroll
       for (int c = 0; c < SB; ++c) x[c] = half ? (c == r ? 1.0 : 0.0) : x[c];
-      if (!half) ucol[r] = x[0];
+      ucol[lane] = x[0];
 #pragma unroll
       for (int c = 1; c < SB; ++c) uc[c] = ucol[c];
       int bad = 0;
-      blk_range<0, SB>(x, uc, un, ucol, &dinv[i0], r, half, bad);
+      blk_range<0, SB>(x, uc, un, ucol, &dinv[i0], lane, bad);
       if (bad && lane == 0) atomicMax(info, kb * TILE + i0 + bad);
       // row r of the image: L[r][c] for c <= r from the low half, X[c][r] (transposed) for
       // c > r from the high half.  Every lane stores every element, the lane that does not
