@@ -30,15 +30,16 @@ __global__ __launch_bounds__(64 * WPB) void loglik_unit_kernel(
   const int u = blockIdx.x * WPB + w;
   if (u >= U) return;
   if (lane <= C) sb[w][lane] = lane == 0 ? -INFINITY : (lane == C ? INFINITY : bthr[lane + (int64_t)(C + 1) * u]);
-  double acc = 0.0;
+  LogProduct prod;
+  prod.reset();
   for (int r = lane; r < n; r += 64) {
     int yy = y[r + ldy * u];
     if (yy > 0) {
       double gg = g[r + ldg * u];
-      acc += ordinal_cell_fast(sb[w][yy - 1] - gg, sb[w][yy] - gg, sphi);
+      prod.mul(ordinal_cell_prob(sb[w][yy - 1] - gg, sb[w][yy] - gg, sphi));
     }
   }
-  acc = wave_sum(acc);
+  double acc = wave_sum(prod.log_value());
   if (lane == 0) ll_unit[u] = acc;
 }
 
@@ -52,17 +53,18 @@ __global__ void loglik_row_kernel(const double *__restrict__ g, int64_t ldg,
   __syncthreads();
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
-  double acc = 0.0;
+  LogProduct prod;
+  prod.reset();
   for (int u = 0; u < U; ++u) {
     int yy = y[r + ldy * u];
     if (yy > 0) {
       const double *b = bthr + (int64_t)(C + 1) * u;
       double lo = yy == 1 ? -INFINITY : b[yy - 1], hi = yy == C ? INFINITY : b[yy];
       double gg = g[r + ldg * u];
-      acc += ordinal_cell_fast(lo - gg, hi - gg, sphi);
+      prod.mul(ordinal_cell_prob(lo - gg, hi - gg, sphi));
     }
   }
-  ll_row[r] = acc;
+  ll_row[r] = prod.log_value();
 }
 
 int launch_loglik(hipStream_t st, const double *g, int64_t ldg, const int8_t *y, int64_t ldy,
@@ -155,7 +157,8 @@ __device__ inline double ll_f_pass(const double *__restrict__ f, const double *_
                                    double b0, double b1, double b2, const int8_t *__restrict__ y,
                                    const double *sb, const double *sphi, int n, int row0, double c,
                                    double s, double *red, int w) {
-  double acc = 0.0;
+  LogProduct prod;
+  prod.reset();
   for (int r = row0; r < n; r += 64 * WPU) {
     int yy = y[r];
     if (yy > 0) {
@@ -164,10 +167,10 @@ __device__ inline double ll_f_pass(const double *__restrict__ f, const double *_
       else { double xr = x[r]; m_r = b0 + b1 * xr + b2 * xr * xr; }
       double pr = f[r] * c + nu[r] * s;
       double gg = m_r + pr;
-      acc += ordinal_cell_fast(sb[yy - 1] - gg, sb[yy] - gg, sphi);
+      prod.mul(ordinal_cell_prob(sb[yy - 1] - gg, sb[yy] - gg, sphi));
     }
   }
-  return unit_sum<WPU>(acc, red, w);
+  return unit_sum<WPU>(prod.log_value(), red, w);
 }
 
 template <int WPU>
@@ -267,16 +270,17 @@ __device__ inline double ll_param_pass(const double *__restrict__ f, const doubl
                                        double b0, double b1, double b2,
                                        const int8_t *__restrict__ y, const double *sb,
                                        const double *sphi, int n, int row0, double *red, int w) {
-  double acc = 0.0;
+  LogProduct prod;
+  prod.reset();
   for (int r = row0; r < n; r += 64 * WPU) {
     int yy = y[r];
     if (yy > 0) {
       double xr = x[r];
       double gg = b0 + b1 * xr + b2 * xr * xr + f[r];
-      acc += ordinal_cell_fast(sb[yy - 1] - gg, sb[yy] - gg, sphi);
+      prod.mul(ordinal_cell_prob(sb[yy - 1] - gg, sb[yy] - gg, sphi));
     }
   }
-  return unit_sum<WPU>(acc, red, w);
+  return unit_sum<WPU>(prod.log_value(), red, w);
 }
 
 template <int WPU>

@@ -47,13 +47,35 @@ __device__ inline double phi_upper(double z, const double *s) {   // Phi(-z), z 
   return e * g;
 }
 
-__device__ inline double ordinal_cell_fast(double zlo, double zhi, const double *s) {
+// P(zlo < Z <= zhi), floored so that a vanished cell stays finite
+__device__ inline double ordinal_cell_prob(double zlo, double zhi, const double *s) {
   zlo = fmax(zlo, -1e30);                      // +-inf thresholds: keep the arithmetic finite
   zhi = fmin(zhi, 1e30);
   const double e1 = phi_upper(fabs(zlo), s), e2 = phi_upper(fabs(zhi), s);
   double p = zlo >= 0.0 ? e1 - e2 : (zhi <= 0.0 ? e2 - e1 : (1.0 - e1) - e2);
   if (!(p > kPFloor)) p = kPFloor;
-  return log(p);
+  return p;
 }
+
+__device__ inline double ordinal_cell_fast(double zlo, double zhi, const double *s) {
+  return log(ordinal_cell_prob(zlo, zhi, s));
+}
+
+// Sum of log-probabilities as the log of their product: the running product is kept as
+// mantissa x 2^exponent (renormalised at every factor, so it never underflows), which costs
+// four instructions per cell where a log costs about thirty; one log per lane at the end.
+// Each factor adds one rounding of relative size 2^-53 to the product, i.e. the same
+// absolute error to the sum of logs -- no worse than adding rounded logs.
+struct LogProduct {
+  double m;
+  int e;
+  __device__ inline void reset() { m = 1.0; e = 0; }
+  __device__ inline void mul(double p) {       // p in [kPFloor, 1]
+    const double q = m * p;
+    m = __builtin_amdgcn_frexp_mant(q);
+    e += __builtin_amdgcn_frexp_exp(q);
+  }
+  __device__ inline double log_value() const { return log(m) + (double)e * 0.69314718055994530942; }
+};
 
 }  // namespace gpirt

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initia
   }
   const int H = a.H, n = a.n, mloc = a.mloc, ML = a.ML, U_pad = a.U_pad;
   const double *b0 = a.betaS, *b1 = a.betaS + U_pad, *b2 = a.betaS + 2 * (int64_t)U_pad;
-  double acc = 0.0;
+  LogProduct prod;
+  prod.reset();
   for (int h = 0; h < H; ++h) {
     double th = initial ? a.theta[i + (int64_t)n * h]
                         : a.prop[i + (int64_t)n * h] + prior_mean(a.tpm, i, h);
@@ -75,11 +76,11 @@ __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initia
         int u = jl + ML * p;
         double gg = Gr[jl] + b0[u] + b1[u] * xg + b2[u] * xg * xg;
         double lo = a.bthrS[u + (int64_t)U_pad * (yy - 1)], hi = a.bthrS[u + (int64_t)U_pad * yy];
-        acc += ordinal_cell_fast(lo - gg, hi - gg, sphi);
+        prod.mul(ordinal_cell_prob(lo - gg, hi - gg, sphi));
       }
     }
   }
-  acc = wave_sum(acc);
+  const double acc = wave_sum(prod.log_value());
   if (lane == 0) a.buf[i] = acc;
 }
 
