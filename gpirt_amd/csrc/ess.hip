@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64 * WPB) void loglik_unit_kernel(
     const double *__restrict__ g, int64_t ldg, const int8_t *__restrict__ y, int64_t ldy,
     const double *__restrict__ bthr, int n, int U, int C, double *__restrict__ ll_unit) {
   __shared__ double sb[WPB][MAXC + 2];
-  __shared__ double sphi[PHI_ROWS * PHI_LD];
+  __shared__ double sphi[PHI_LDS_DOUBLES];
   phi_table_to_lds(sphi);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -48,7 +48,7 @@ __global__ void loglik_row_kernel(const double *__restrict__ g, int64_t ldg,
                                   const int8_t *__restrict__ y, int64_t ldy,
                                   const double *__restrict__ bthr, int n, int U, int C,
                                   double *__restrict__ ll_row) {
-  __shared__ double sphi[PHI_ROWS * PHI_LD];
+  __shared__ double sphi[PHI_LDS_DOUBLES];
   phi_table_to_lds(sphi);
   __syncthreads();
   int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -176,7 +176,7 @@ __device__ inline double ll_f_pass(const double *__restrict__ f, const double *_
 template <int WPU>
 __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
   __shared__ double sbb[WPB][MAXC + 2];
-  __shared__ double sphi[PHI_ROWS * PHI_LD];
+  __shared__ double sphi[PHI_LDS_DOUBLES];
   __shared__ double red[WPB];
   phi_table_to_lds(sphi);
   __syncthreads();
@@ -286,7 +286,7 @@ __device__ inline double ll_param_pass(const double *__restrict__ f, const doubl
 template <int WPU>
 __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
   __shared__ double sbb[WPB][MAXC + 2];
-  __shared__ double sphi[PHI_ROWS * PHI_LD];
+  __shared__ double sphi[PHI_LDS_DOUBLES];
   __shared__ double red[WPB];
   phi_table_to_lds(sphi);
   __syncthreads();

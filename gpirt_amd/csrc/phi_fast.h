@@ -18,13 +18,36 @@ constexpr int PHI_ROWS = GPIRT_PHI_K;
 constexpr int PHI_NC = GPIRT_PHI_DEG + 1;
 constexpr int PHI_LD = 9;   // LDS row stride (doubles): 72-byte rows spread the gathers over banks
 
+constexpr int EXP_TAB = 64;  // 2^(j/64), j = 0..63, behind the polynomial table
+constexpr int PHI_LDS_DOUBLES = PHI_ROWS * PHI_LD + EXP_TAB;
+
 // every thread of the workgroup calls this once, followed by __syncthreads()
 __device__ inline void phi_table_to_lds(double *s) {
   for (int e = threadIdx.x; e < PHI_ROWS * PHI_NC; e += blockDim.x)
     s[(e / PHI_NC) * PHI_LD + (e % PHI_NC)] = kPhiTab[e];
+  for (int j = threadIdx.x; j < EXP_TAB; j += blockDim.x)
+    s[PHI_ROWS * PHI_LD + j] = exp2((double)j * (1.0 / EXP_TAB));
+}
+
+// exp(h + l) for h <= 0 and a tiny correction l: h = (64 m + j) ln2/64 + r with |r| <= ln2/128,
+// 2^(j/64) from the table, exp(r) - 1 from a degree-5 polynomial (remainder 3e-17), scaled
+// by 2^m.  Branch-free; underflows gradually to zero.
+__device__ inline double exp_neg(double h, double l, const double *s) {
+  const double hc = fmax(h, -745.5);
+  const double nf = rint(hc * 92.33248261689366);              // 64 / ln 2
+  double r = fma(nf, -0.010830424695086549, hc);                // ln2/64 high part (33 bits: exact product)
+  r = fma(nf, -1.162596423439437e-12, r) + l;                   // low part
+  const int n = (int)nf;
+  const double t = s[PHI_ROWS * PHI_LD + (n & (EXP_TAB - 1))];
+  double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  q = fma(q, r, 1.0 / 6.0);
+  q = fma(q, r, 0.5);
+  q = fma(q, r, 1.0);
+  return ldexp(fma(t, q * r, t), n >> 6);
 }
 
 __device__ inline double phi_upper(double z, const double *s) {   // Phi(-z), z >= 0
+  z = fmin(z, 40.0);                          // Phi(-40) is far below the smallest double
   const double d = 1.0 + 0.5 * z;
   double u = __builtin_amdgcn_rcp(d);
   u = fma(u, fma(-d, u, 1.0), u);
@@ -41,10 +64,8 @@ __device__ inline double phi_upper(double z, const double *s) {   // Phi(-z), z 
   g = fma(g, t, c[1]);
   g = fma(g, t, c[0]);
   const double h = -0.5 * z * z;
-  const double l = fma(-0.5 * z, z, -h);      // rounding error of h, folded back in below
-  double e = exp(h);
-  e = fma(e, l, e);
-  return e * g;
+  const double l = fma(-0.5 * z, z, -h);      // rounding error of h, folded into the exponent
+  return exp_neg(h, l, s) * g;
 }
 
 // P(zlo < Z <= zhi), floored so that a vanished cell stays finite

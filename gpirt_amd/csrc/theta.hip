@@ -48,7 +48,7 @@ int launch_theta_prepare(hipStream_t st, const ThetaArgs &a) {
 
 // local-items log-likelihood of every active respondent, one wave per respondent
 __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initial) {
-  __shared__ double sphi[PHI_ROWS * PHI_LD];
+  __shared__ double sphi[PHI_LDS_DOUBLES];
   phi_table_to_lds(sphi);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -156,7 +156,7 @@ int launch_grid_onehot(hipStream_t st, const int8_t *yT, int n, int mloc, int ML
 
 // T[g + G_pad*(jl + ML*c)] = log-probability of category c+1 for item jl at grid point g
 __global__ __launch_bounds__(256) void grid_table_kernel(ThetaArgs a, int G_pad, double *__restrict__ T) {
-  __shared__ double sphi[PHI_ROWS * PHI_LD];
+  __shared__ double sphi[PHI_LDS_DOUBLES];
   phi_table_to_lds(sphi);
   __syncthreads();
   const int g = blockIdx.x * blockDim.x + threadIdx.x, jl = blockIdx.y;
