@@ -157,18 +157,25 @@ __device__ inline double ll_f_pass(const double *__restrict__ f, const double *_
                                    double b0, double b1, double b2, const int8_t *__restrict__ y,
                                    const double *sb, const double *sphi, int n, int row0, double c,
                                    double s, double *red, int w) {
+  // Software-pipelined and branch-free: the loads of the next row are in flight while the
+  // current cell is evaluated (a wave that waits for y before it asks for f pays two memory
+  // round trips per row, and four waves per SIMD do not hide that).  Indices past the end
+  // are clamped to the last row and their cells masked out.
   LogProduct prod;
   prod.reset();
+  if (row0 >= n) return unit_sum<WPU>(0.0, red, w);
+  int yy = y[row0];
+  double fr = f[row0], nr = nu[row0], xr = mu ? mu[row0] : x[row0];
   for (int r = row0; r < n; r += 64 * WPU) {
-    int yy = y[r];
-    if (yy > 0) {
-      double m_r;
-      if (mu) m_r = mu[r];
-      else { double xr = x[r]; m_r = b0 + b1 * xr + b2 * xr * xr; }
-      double pr = f[r] * c + nu[r] * s;
-      double gg = m_r + pr;
-      prod.mul(ordinal_cell_prob(sb[yy - 1] - gg, sb[yy] - gg, sphi));
-    }
+    const int rn = min(r + 64 * WPU, n - 1);
+    const int yn = y[rn];
+    const double fn = f[rn], nn = nu[rn], xn = mu ? mu[rn] : x[rn];
+    const double m_r = mu ? xr : b0 + b1 * xr + b2 * xr * xr;
+    const double gg = m_r + (fr * c + nr * s);
+    const int yc = max(yy, 1);
+    const double p = ordinal_cell_prob(sb[yc - 1] - gg, sb[yc] - gg, sphi);
+    prod.mul(yy > 0 ? p : 1.0);
+    yy = yn; fr = fn; nr = nn; xr = xn;
   }
   return unit_sum<WPU>(prod.log_value(), red, w);
 }
@@ -270,15 +277,20 @@ __device__ inline double ll_param_pass(const double *__restrict__ f, const doubl
                                        double b0, double b1, double b2,
                                        const int8_t *__restrict__ y, const double *sb,
                                        const double *sphi, int n, int row0, double *red, int w) {
-  LogProduct prod;
+  LogProduct prod;                       // pipelined like ll_f_pass
   prod.reset();
+  if (row0 >= n) return unit_sum<WPU>(0.0, red, w);
+  int yy = y[row0];
+  double fr = f[row0], xr = x[row0];
   for (int r = row0; r < n; r += 64 * WPU) {
-    int yy = y[r];
-    if (yy > 0) {
-      double xr = x[r];
-      double gg = b0 + b1 * xr + b2 * xr * xr + f[r];
-      prod.mul(ordinal_cell_prob(sb[yy - 1] - gg, sb[yy] - gg, sphi));
-    }
+    const int rn = min(r + 64 * WPU, n - 1);
+    const int yn = y[rn];
+    const double fn = f[rn], xn = x[rn];
+    const double gg = b0 + b1 * xr + b2 * xr * xr + fr;
+    const int yc = max(yy, 1);
+    const double p = ordinal_cell_prob(sb[yc - 1] - gg, sb[yc] - gg, sphi);
+    prod.mul(yy > 0 ? p : 1.0);
+    yy = yn; fr = fn; xr = xn;
   }
   return unit_sum<WPU>(prod.log_value(), red, w);
 }

@@ -70,14 +70,25 @@ __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initia
     const int p = a.constant_irf ? 0 : h;
     const double *Gr = a.Gt + (int64_t)U_pad * g + (int64_t)ML * p;
     const int8_t *yr = a.yT + (int64_t)ML * H * i + (int64_t)ML * h;
+    if (lane >= mloc) continue;
+    // software-pipelined, branch-free: y runs two items ahead (the thresholds are gathered by
+    // category), everything else one item ahead; indices past the end are clamped to the
+    // last item and those cells masked
+    const int jend = mloc - 1, up = ML * p;
+    int y1 = yr[lane], y2 = yr[min(lane + 64, jend)];
+    int yc = max(y1, 1);
+    double G1 = Gr[lane], c0 = b0[up + lane], c1 = b1[up + lane], c2 = b2[up + lane];
+    double lo = a.bthrS[up + lane + (int64_t)U_pad * (yc - 1)], hi = a.bthrS[up + lane + (int64_t)U_pad * yc];
     for (int jl = lane; jl < mloc; jl += 64) {
-      int yy = yr[jl];
-      if (yy > 0) {
-        int u = jl + ML * p;
-        double gg = Gr[jl] + b0[u] + b1[u] * xg + b2[u] * xg * xg;
-        double lo = a.bthrS[u + (int64_t)U_pad * (yy - 1)], hi = a.bthrS[u + (int64_t)U_pad * yy];
-        prod.mul(ordinal_cell_prob(lo - gg, hi - gg, sphi));
-      }
+      const int jn = min(jl + 64, jend), un = up + jn;
+      const int y3 = yr[min(jl + 128, jend)];
+      const int ycn = max(y2, 1);
+      const double Gn = Gr[jn], d0 = b0[un], d1 = b1[un], d2 = b2[un];
+      const double lon = a.bthrS[un + (int64_t)U_pad * (ycn - 1)], hin = a.bthrS[un + (int64_t)U_pad * ycn];
+      const double gg = G1 + c0 + c1 * xg + c2 * xg * xg;
+      const double pc = ordinal_cell_prob(lo - gg, hi - gg, sphi);
+      prod.mul(y1 > 0 ? pc : 1.0);
+      y1 = y2; y2 = y3; G1 = Gn; c0 = d0; c1 = d1; c2 = d2; lo = lon; hi = hin;
     }
   }
   const double acc = wave_sum(prod.log_value());
