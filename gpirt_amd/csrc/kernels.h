@@ -67,11 +67,11 @@ struct ThetaArgs {
   double grid_lo, grid_step;
   double os2;               // prior variance of the static step (theta_os^2, 1 when theta_os = 0)
   uint64_t seed; uint32_t sweep;
-  int32_t *remaining;       // device counter
+  int32_t *remaining;       // [R+1] respondents still active after the decision of round r
   unsigned long long *counters;  // [1] capped
 };
 int launch_theta_prepare(hipStream_t st, const ThetaArgs &a);
-int launch_theta_eval(hipStream_t st, const ThetaArgs &a, int initial);
+int launch_theta_eval(hipStream_t st, const ThetaArgs &a, int initial, bool wide);
 int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int round);
 // static (grid) respondent step, H = 1: one-hot coding of y (k = jl + ML*(y-1), ld = C*ML),
 // the per-sweep table of log cell probabilities T[G_pad, C*ML], and the inverse-CDF draw

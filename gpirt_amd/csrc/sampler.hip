@@ -276,7 +276,7 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   A_(s->d_Lt, (size_t)H * H);
   A_(s->d_tpm, 2 * (size_t)n); A_(s->d_tps, 2 * (size_t)n);
   A_(s->d_llu, U_pad);
-  A_(s->d_done, n); A_(s->d_info, 1); A_(s->d_remaining, 1);
+  A_(s->d_done, n); A_(s->d_info, 1); A_(s->d_remaining, (size_t)(s->cfg.max_ess_rounds + 2));
   A_(s->d_counters, 6);
   if (cfg->theta_mode == GPIRT_THETA_GRID) {
     A_(s->d_onehot, (size_t)C * ML * Np_pad);
@@ -484,25 +484,44 @@ static int exchange(gpirt_sampler *s, double *buf = nullptr, int64_t count = 0) 
   return GPIRT_OK;
 }
 
+// Lock-step rounds.  The decision kernel of round r leaves the number of respondents still
+// active in remaining[r]; the host looks at that history only every few rounds (a look is a
+// stream drain plus a launch gap, dearer than a round in which nobody is active any more),
+// except with sharded items, where every round passes through the host for the exchange.
 static int phase_theta(gpirt_sampler *s) {
   GP_TRY(mark(s, PH_THETA));
   ThetaArgs a = theta_args(s);
+  const int R = a.R;
+  const bool sharded = s->cfg.world > 1;
+  GP_HIP(hipMemsetAsync(s->d_remaining, 0, sizeof(int) * (size_t)(R + 2), s->st));
   GP_TRY(launch_theta_prepare(s->st, a));
-  GP_TRY(launch_theta_eval(s->st, a, 1));
+  GP_TRY(launch_theta_eval(s->st, a, 1, false));
   GP_TRY(exchange(s));
   s->theta_rounds++;
-  GP_HIP(hipMemsetAsync(s->d_remaining, 0, sizeof(int), s->st));
   GP_TRY(launch_theta_decide(s->st, a, 0));
-  for (int r = 1; r <= a.R; ++r) {
-    GP_TRY(launch_theta_eval(s->st, a, 0));
-    GP_TRY(exchange(s));
-    s->theta_rounds++;
-    GP_HIP(hipMemsetAsync(s->d_remaining, 0, sizeof(int), s->st));
-    GP_TRY(launch_theta_decide(s->st, a, r));
-    int remaining = 0;
-    GP_HIP(hipMemcpyAsync(&remaining, s->d_remaining, sizeof(int), hipMemcpyDeviceToHost, s->st));
+  std::vector<int> hist((size_t)R + 2, 0);
+  int active = s->n;
+  int r = 1;
+  while (r <= R) {
+    // rounds r .. last run without a look at the counters
+    const int last = sharded ? r : min(R, r < 6 ? 6 : r + 2);
+    const bool wide = active * 4 <= s->n;
+    for (int q = r; q <= last; ++q) {
+      GP_TRY(launch_theta_eval(s->st, a, 0, wide));
+      GP_TRY(exchange(s));
+      GP_TRY(launch_theta_decide(s->st, a, q));
+    }
+    GP_HIP(hipMemcpyAsync(hist.data() + r, s->d_remaining + r, sizeof(int) * (size_t)(last - r + 1),
+                          hipMemcpyDeviceToHost, s->st));
     GP_HIP(hipStreamSynchronize(s->st));
-    if (!remaining) break;
+    bool finished = false;
+    for (int q = r; q <= last; ++q) {
+      s->theta_rounds++;
+      active = hist[q];
+      if (!active) { finished = true; break; }    // rounds after q (if any) found nobody active
+    }
+    if (finished) break;
+    r = last + 1;
   }
   return GPIRT_OK;
 }

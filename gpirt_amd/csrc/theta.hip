@@ -46,19 +46,25 @@ int launch_theta_prepare(hipStream_t st, const ThetaArgs &a) {
   return GPIRT_OK;
 }
 
-// local-items log-likelihood of every active respondent, one wave per respondent
+// local-items log-likelihood of every active respondent.  WPR = 1: one wave per respondent
+// (four respondents per workgroup).  WPR = 4: the four waves of a workgroup share one
+// respondent -- for the late rounds, when few respondents are still active and the time of a
+// round is the latency of one respondent's loop rather than the chip's throughput.
+template <int WPR>
 __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initial) {
   __shared__ double sphi[PHI_LDS_DOUBLES];
+  __shared__ double red[4];
   phi_table_to_lds(sphi);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + w;
+  const int i = WPR == 1 ? blockIdx.x * 4 + w : blockIdx.x;
   if (i >= a.n) return;
-  if (!initial && a.done[i]) {
-    if (lane == 0) a.buf[i] = 0.0;
+  if (!initial && a.done[i]) {               // uniform over the workgroup when WPR = 4
+    if (lane == 0 && (WPR == 1 || w == 0)) a.buf[i] = 0.0;
     return;
   }
   const int H = a.H, n = a.n, mloc = a.mloc, ML = a.ML, U_pad = a.U_pad;
+  const int jfirst = WPR == 1 ? lane : lane + 64 * w, jstep = 64 * WPR;
   const double *b0 = a.betaS, *b1 = a.betaS + U_pad, *b2 = a.betaS + 2 * (int64_t)U_pad;
   LogProduct prod;
   prod.reset();
@@ -70,18 +76,18 @@ __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initia
     const int p = a.constant_irf ? 0 : h;
     const double *Gr = a.Gt + (int64_t)U_pad * g + (int64_t)ML * p;
     const int8_t *yr = a.yT + (int64_t)ML * H * i + (int64_t)ML * h;
-    if (lane >= mloc) continue;
+    if (jfirst >= mloc) continue;
     // software-pipelined, branch-free: y runs two items ahead (the thresholds are gathered by
     // category), everything else one item ahead; indices past the end are clamped to the
     // last item and those cells masked
     const int jend = mloc - 1, up = ML * p;
-    int y1 = yr[lane], y2 = yr[min(lane + 64, jend)];
+    int y1 = yr[jfirst], y2 = yr[min(jfirst + jstep, jend)];
     int yc = max(y1, 1);
-    double G1 = Gr[lane], c0 = b0[up + lane], c1 = b1[up + lane], c2 = b2[up + lane];
-    double lo = a.bthrS[up + lane + (int64_t)U_pad * (yc - 1)], hi = a.bthrS[up + lane + (int64_t)U_pad * yc];
-    for (int jl = lane; jl < mloc; jl += 64) {
-      const int jn = min(jl + 64, jend), un = up + jn;
-      const int y3 = yr[min(jl + 128, jend)];
+    double G1 = Gr[jfirst], c0 = b0[up + jfirst], c1 = b1[up + jfirst], c2 = b2[up + jfirst];
+    double lo = a.bthrS[up + jfirst + (int64_t)U_pad * (yc - 1)], hi = a.bthrS[up + jfirst + (int64_t)U_pad * yc];
+    for (int jl = jfirst; jl < mloc; jl += jstep) {
+      const int jn = min(jl + jstep, jend), un = up + jn;
+      const int y3 = yr[min(jl + 2 * jstep, jend)];
       const int ycn = max(y2, 1);
       const double Gn = Gr[jn], d0 = b0[un], d1 = b1[un], d2 = b2[un];
       const double lon = a.bthrS[un + (int64_t)U_pad * (ycn - 1)], hin = a.bthrS[un + (int64_t)U_pad * ycn];
@@ -92,11 +98,18 @@ __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initia
     }
   }
   const double acc = wave_sum(prod.log_value());
-  if (lane == 0) a.buf[i] = acc;
+  if (WPR == 1) {
+    if (lane == 0) a.buf[i] = acc;
+  } else {
+    if (lane == 0) red[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) a.buf[i] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
 }
 
-int launch_theta_eval(hipStream_t st, const ThetaArgs &a, int initial) {
-  hipLaunchKernelGGL(theta_eval_kernel, dim3((a.n + 3) / 4), dim3(256), 0, st, a, initial);
+int launch_theta_eval(hipStream_t st, const ThetaArgs &a, int initial, bool wide) {
+  if (wide) hipLaunchKernelGGL(theta_eval_kernel<4>, dim3(a.n), dim3(256), 0, st, a, initial);
+  else hipLaunchKernelGGL(theta_eval_kernel<1>, dim3((a.n + 3) / 4), dim3(256), 0, st, a, initial);
   GP_HIP(hipGetLastError());
   return GPIRT_OK;
 }
@@ -134,7 +147,7 @@ __global__ void theta_decide_kernel(ThetaArgs a, int round) {
   sincos(phi, &s, &c);
   for (int h = 0; h < H; ++h)
     a.prop[i + (int64_t)n * h] = a.xc[i + (int64_t)n * h] * c + a.nu[i + (int64_t)n * h] * s;
-  atomicAdd(a.remaining, 1);
+  atomicAdd(&a.remaining[round], 1);
 }
 
 int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int round) {
