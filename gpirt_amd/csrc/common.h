@@ -168,6 +168,9 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
 // xtmp holds 4 * SUP * nrhs_pad doubles per system (split-K slabs of the diagonal steps).
 int launch_potrs(hipStream_t st, const double *L, const double *inv, int n_pad, int batch,
                  double *B, int64_t ldb, int64_t strideB, int nrhs_pad, double *xtmp);
+// out[r + ldo*j] = sum_q x[q*slab_stride + r + ldx*j], rows even (split-K partial results)
+int launch_sum_slabs(hipStream_t st, const double *x, int nslab, int64_t slab_stride, int rows,
+                     int cols, int64_t ldx, double *out, int64_t ldo);
 // Kst[r + n_pad*g] = sf^2 exp(-(xs_g - x_r)^2 / (2 ls^2)), zero outside r<n, g<G.
 int launch_kstar_t(hipStream_t st, const double *x, int64_t x_stride, int n, int n_pad, int batch,
                    double ls, double sf, int G, int G_pad, double lo, double step, double *Kst);

@@ -557,6 +557,14 @@ __global__ void sum_slabs_kernel(const double *__restrict__ x, int nslab, int64_
   *reinterpret_cast<double2 *>(out + r + ldo * j) = acc;
 }
 
+int launch_sum_slabs(hipStream_t st, const double *x, int nslab, int64_t slab_stride, int rows,
+                     int cols, int64_t ldx, double *out, int64_t ldo) {
+  dim3 grid((rows / 2 + 255) / 256, cols);
+  hipLaunchKernelGGL(sum_slabs_kernel, grid, dim3(256), 0, st, x, nslab, slab_stride, rows, ldx, out, ldo);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
 // Two blocked triangular solves, SUP rows per step: the diagonal step is a product with the
 // inverted super-block (written to xtmp, then copied back over B's rows), followed by one
 // rank-SUP update of the remaining rows.

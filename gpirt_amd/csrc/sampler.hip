@@ -444,16 +444,47 @@ static int phase_param(gpirt_sampler *s) {
 
 static int phase_fstar(gpirt_sampler *s) {
   GP_TRY(mark(s, PH_FSTAR));
-  // W = S^-1 K(x, xs); then f*^T = F^T W   (gp posterior mean, main.m:57-58)
+  // f*^T = F^T S^-1 K(x, xs)   (gp posterior mean, main.m:57-58).  The solve goes to whichever
+  // side has fewer columns: W = S^-1 K(x,xs) (G columns, the same on every rank) or
+  // alpha = S^-1 F (this rank's units: fewer than G once the items are sharded, and then no
+  // rank repeats another's solve).
   GP_TRY(launch_kstar_t(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
                         s->cfg.irf_sf, s->G, s->G_pad, s->cfg.grid_lo, s->cfg.grid_step, s->d_W));
-  GP_TRY(launch_potrs(s->st, s->d_S, s->d_inv, s->Np_pad, s->P, s->d_W, s->Np_pad,
-                      (int64_t)s->Np_pad * s->G_pad, s->G_pad, s->d_xtmp));
+  const double *lhs = s->d_f;
+  if (s->ML < s->G_pad) {
+    // nu is free between the f step and the next sweep: alpha is built there
+    GP_HIP(hipMemcpyAsync(s->d_nu, s->d_f, sizeof(double) * (size_t)s->Np_pad * s->U_pad,
+                          hipMemcpyDeviceToDevice, s->st));
+    GP_TRY(launch_potrs(s->st, s->d_S, s->d_inv, s->Np_pad, s->P, s->d_nu, s->Np_pad,
+                        (int64_t)s->Np_pad * s->ML, s->ML, s->d_xtmp));
+    lhs = s->d_nu;
+  } else {
+    GP_TRY(launch_potrs(s->st, s->d_S, s->d_inv, s->Np_pad, s->P, s->d_W, s->Np_pad,
+                        (int64_t)s->Np_pad * s->G_pad, s->G_pad, s->d_xtmp));
+  }
   GemmArgs g{};
-  g.A = s->d_f; g.lda = s->Np_pad; g.strideA = (int64_t)s->Np_pad * s->ML;
+  g.A = lhs; g.lda = s->Np_pad; g.strideA = (int64_t)s->Np_pad * s->ML;
   g.B = s->d_W; g.ldb = s->Np_pad; g.strideB = (int64_t)s->Np_pad * s->G_pad;
   g.C = s->d_Gt; g.ldc = s->U_pad; g.strideC = s->ML;
   g.M = s->ML; g.N = s->G_pad; g.K = s->Np_pad; g.batch = s->P; g.alpha = 1.0; g.beta = 0.0;
+  // Few output tiles and a long K: split K over the GEMM's batch index (one group only) into
+  // partial products parked in Z (free until the next sweep's draws), summed afterwards.
+  const int64_t tiles = (int64_t)(s->ML / TILE) * (s->G_pad / TILE);
+  int splits = 1;
+  if (s->P == 1 && tiles < 512 && s->Np_pad >= 2048) {
+    const int slabs = s->Np_pad / 16;
+    const int64_t room = ((int64_t)s->Np_pad * s->U_pad) / ((int64_t)s->ML * s->G_pad);
+    for (int q = 2; q <= 16 && q <= room && tiles * q <= 1024; ++q)
+      if (slabs % q == 0) splits = q;
+  }
+  if (splits > 1) {
+    const int kc = s->Np_pad / splits;
+    g.K = kc; g.batch = splits; g.strideA = kc; g.strideB = kc;
+    g.C = s->d_Z; g.ldc = s->ML; g.strideC = (int64_t)s->ML * s->G_pad;
+    GP_TRY(launch_gemm(s->st, true, false, g));
+    GP_TRY(launch_sum_slabs(s->st, s->d_Z, splits, g.strideC, s->ML, s->G_pad, s->ML, s->d_Gt, s->U_pad));
+    return GPIRT_OK;
+  }
   GP_TRY(launch_gemm(s->st, true, false, g));
   return GPIRT_OK;
 }

@@ -186,20 +186,38 @@ def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const):
     g.close(); c.close()
 
 
-def test_sweep_matches_oracle_wide_units():
+@pytest.mark.parametrize("n,m,sweeps", [(1300, 9, 2), (2100, 5, 1)])
+def test_sweep_matches_oracle_wide_units(n, m, sweeps):
     """n >= 1024 rows per unit switches the item kernels to one workgroup per unit and the
-    Cholesky to several diagonal blocks (ragged last super-block): same parity bar."""
+    Cholesky to several diagonal blocks (ragged last super-block); n >= 2048 also splits the
+    K range of the f* product into partial sums: same parity bar."""
     from gpirt_amd.synth import generate
-    d = generate(1300, 9, 3, seed=4)
-    cfg = _abi.default_config(n=1300, m=9, H=1, C=3, seed=8)
+    d = generate(n, m, 3, seed=4)
+    cfg = _abi.default_config(n=n, m=m, H=1, C=3, seed=8)
     g, c = _pair(cfg, d["y"], theta_init=d["theta"])
-    for sweep in range(2):
+    for sweep in range(sweeps):
         g.sweep(1); c.sweep(1)
         sg, sc = g.state(), c.state()
         for k in ("theta", "beta", "f", "fstar"):
             assert np.abs(sg[k] - sc[k]).max() < 1e-5, (sweep, k)
         fin = np.isfinite(sc["threshold"])
         assert np.abs(sg["threshold"][fin] - sc["threshold"][fin]).max() < 1e-5
+    assert g.diagnostics() == c.diagnostics()
+    g.close(); c.close()
+
+
+def test_sweep_matches_oracle_many_items():
+    """More unit columns than grid points (ML >= G_pad = 1024): the f* phase then solves
+    S^-1 K(x, xs) instead of S^-1 F.  Same parity bar."""
+    from gpirt_amd.synth import generate
+    d = generate(70, 1030, 3, seed=6)
+    cfg = _abi.default_config(n=70, m=1030, H=1, C=3, seed=2)
+    g, c = _pair(cfg, d["y"], theta_init=d["theta"])
+    for sweep in range(2):
+        g.sweep(1); c.sweep(1)
+        sg, sc = g.state(), c.state()
+        for k in ("theta", "beta", "f", "fstar"):
+            assert np.abs(sg[k] - sc[k]).max() < 1e-5, (sweep, k)
     assert g.diagnostics() == c.diagnostics()
     g.close(); c.close()
 
