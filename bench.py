@@ -119,7 +119,10 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        hook = torch_allreduce(device_buffers=True)
+        # stream-ordered hook: the collective is enqueued on the sampler's own HIP stream, no
+        # host round trip per proposal round (GPIRT_BENCH_SYNC_ALLREDUCE=1: the blocking hook)
+        on_stream = not os.environ.get("GPIRT_BENCH_SYNC_ALLREDUCE")
+        hook = torch_allreduce(device_buffers=True, on_stream=on_stream)
 
     n, m, C = args.n, args.m, args.C
     data = generate(n, m, C, seed=args.seed)          # identical on every rank
@@ -132,8 +135,12 @@ def main():
         cfg.item_begin, cfg.item_end = item_range(m, rank, world)
         keep = _abi.ALLREDUCE_FN(lambda ptr, count, user: hook(ptr, count))
         cfg.allreduce = keep
+        if on_stream:
+            cfg.flags |= _abi.ALLREDUCE_ON_STREAM
     s = Sampler(cfg, data["y"], theta_init=theta_init, beta_prior_means=np.zeros((3, m)),
                 beta_prior_sds=np.ones((3, m)))
+    if hook is not None:
+        hook.stream_ptr = s.stream()
 
     def barrier():
         if dist is not None:

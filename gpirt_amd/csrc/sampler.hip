@@ -506,7 +506,7 @@ static ThetaArgs theta_args(gpirt_sampler *s) {
 // sum the per-respondent partial log-likelihoods over the ranks that share the chain
 static int exchange(gpirt_sampler *s, double *buf = nullptr, int64_t count = 0) {
   if (s->cfg.world <= 1) return GPIRT_OK;
-  GP_HIP(hipStreamSynchronize(s->st));
+  if (!(s->cfg.flags & GPIRT_ALLREDUCE_ON_STREAM)) GP_HIP(hipStreamSynchronize(s->st));
   if (!buf) { buf = s->d_buf; count = s->n; }
   if (s->cfg.allreduce(buf, count, s->cfg.allreduce_user)) {
     set_error("allreduce hook failed");
@@ -523,7 +523,8 @@ static int phase_theta(gpirt_sampler *s) {
   GP_TRY(mark(s, PH_THETA));
   ThetaArgs a = theta_args(s);
   const int R = a.R;
-  const bool sharded = s->cfg.world > 1;
+  // a hook that is not stream-ordered passes through the host every round anyway
+  const bool sharded = s->cfg.world > 1 && !(s->cfg.flags & GPIRT_ALLREDUCE_ON_STREAM);
   GP_HIP(hipMemsetAsync(s->d_remaining, 0, sizeof(int) * (size_t)(R + 2), s->st));
   GP_TRY(launch_theta_prepare(s->st, a));
   GP_TRY(launch_theta_eval(s->st, a, 1, false));

@@ -23,25 +23,44 @@ class _DevVec:
             "strides": None}
 
 
-def torch_allreduce(group=None, device_buffers=True, via_host=False):
+def torch_allreduce(group=None, device_buffers=True, via_host=False, on_stream=False):
     """Return ``f(ptr, count) -> 0`` summing `count` doubles at `ptr` over the process group,
     in place.  `device_buffers=True`: `ptr` is HBM on the current device (HIP backend);
     False: `ptr` is host memory (CPU rehearsal with gloo).  `via_host=True` stages a device
     buffer through host memory so that a gloo group can carry it (several ranks sharing one
-    GPU in a test; RCCL refuses two ranks on one device)."""
+    GPU in a test; RCCL refuses two ranks on one device).
+
+    `on_stream=True` (device buffers, RCCL): the collective is enqueued behind the work
+    already on the sampler's HIP stream and the hook returns at once -- set
+    ``hook.stream_ptr = sampler.stream()`` after creating the sampler and
+    ``ALLREDUCE_ON_STREAM`` in ``cfg.flags`` before.  No host round trip per proposal round."""
     import torch
     import torch.distributed as dist
 
+    views = {}
+
+    def view(ptr, count):
+        key = (int(ptr), int(count))
+        if key not in views:
+            views[key] = torch.as_tensor(_DevVec(ptr, count), device="cuda")
+        return views[key]
+
     def hook(ptr, count):
         if device_buffers and via_host:
-            t = torch.as_tensor(_DevVec(ptr, count), device="cuda")
+            t = view(ptr, count)
             h = t.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
             t.copy_(h)
             torch.cuda.current_stream().synchronize()
+        elif device_buffers and on_stream:
+            if hook.stream_ptr is None:
+                raise RuntimeError("on_stream hook: set hook.stream_ptr = sampler.stream() first")
+            if hook._ext is None:
+                hook._ext = torch.cuda.ExternalStream(int(hook.stream_ptr))
+            with torch.cuda.stream(hook._ext):
+                dist.all_reduce(view(ptr, count), op=dist.ReduceOp.SUM, group=group)
         elif device_buffers:
-            t = torch.as_tensor(_DevVec(ptr, count), device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(view(ptr, count), op=dist.ReduceOp.SUM, group=group)
             torch.cuda.current_stream().synchronize()
         else:
             arr = np.ctypeslib.as_array((C.c_double * count).from_address(ptr))
@@ -49,4 +68,6 @@ def torch_allreduce(group=None, device_buffers=True, via_host=False):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         return 0
 
+    hook.stream_ptr = None
+    hook._ext = None
     return hook

@@ -60,13 +60,19 @@ typedef enum gpirt_theta_mode {
 
 enum {
   GPIRT_RETURN_F = 1,      /* copy each kept draw of f back (large: n*m*H doubles per draw) */
-  GPIRT_RETURN_FSTAR = 2   /* copy each kept draw of f* back (n_grid*m*P doubles per draw)  */
+  GPIRT_RETURN_FSTAR = 2,  /* copy each kept draw of f* back (n_grid*m*P doubles per draw)  */
+  GPIRT_ALLREDUCE_ON_STREAM = 4 /* the all-reduce hook ENQUEUES the collective on the sampler's
+                              HIP stream (gpirt_sampler_stream) and returns without waiting;
+                              the library then does not drain the stream around the call and
+                              looks at the round counters only every few rounds               */
 };
 
 /* Sum-all-reduce hook used by the respondent step when items are sharded over
  * ranks: must leave, in place, the element-wise sum over all ranks of `count`
  * doubles at `buf` on every rank.  `buf` is a DEVICE pointer for the HIP
- * backend and a host pointer for the CPU oracle.  Return 0 on success. */
+ * backend and a host pointer for the CPU oracle.  Return 0 on success.  Unless
+ * GPIRT_ALLREDUCE_ON_STREAM is set, the sampler's stream is idle during the call and
+ * the result must be complete when the hook returns. */
 typedef int (*gpirt_allreduce_fn)(double *buf, int64_t count, void *user);
 
 /* Called once per finished sweep on the calling thread (the place for

@@ -105,3 +105,49 @@ def test_rccl_hook_on_a_raw_device_pointer(tmp_path):
     out = os.path.join(str(tmp_path), "r.txt")
     mp.spawn(_nccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
     assert open(out).read() == "ok"
+
+
+def _onstream_worker(rank, world, port, out_dir):
+    """One RCCL rank that plays rank 0 of 2 (it owns the first half of the items): the chain
+    is not a valid posterior sample, but the stream-ordered hook and the blocking hook must
+    drive it to the same state."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from gpirt_amd import _abi
+    from gpirt_amd.dist import item_range, torch_allreduce
+    from gpirt_amd.sampler import Sampler
+    from conftest import load_fixture
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    d = load_fixture("Wiener_C_5")
+    y, theta = d["y"][:, :, :3], d["theta"][:, :3]
+    n, m, H = y.shape
+    j0, j1 = item_range(m, 0, 2)
+    states = []
+    for on_stream in (False, True):
+        hook = torch_allreduce(device_buffers=True, on_stream=on_stream)
+        cb = _abi.ALLREDUCE_FN(lambda ptr, count, user: hook(ptr, count))
+        cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=11, theta_ls=1.5, item_begin=j0, item_end=j1,
+                                  rank=0, world=2,
+                                  flags=_abi.ALLREDUCE_ON_STREAM if on_stream else 0)
+        cfg.allreduce = cb
+        s = Sampler(cfg, y, theta_init=theta)
+        hook.stream_ptr = s.stream()
+        s.sweep(3)
+        states.append((s.state(), s.diagnostics()))
+        s.close()
+    ok = states[0][1] == states[1][1] and all(
+        np.array_equal(states[0][0][k], states[1][0][k]) for k in ("theta", "f", "fstar", "beta"))
+    open(os.path.join(out_dir, "r.txt"), "w").write("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+def test_stream_ordered_rccl_hook_matches_blocking_hook(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_onstream_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert open(os.path.join(str(tmp_path), "r.txt")).read() == "ok"
