@@ -61,6 +61,17 @@ class GpirtConfig(C.Structure):
     ]
 
 
+class GpirtSummary(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("draws", C.c_int32),
+        ("theta_mean", C.POINTER(C.c_double)),
+        ("theta_sd", C.POINTER(C.c_double)),
+        ("prob_mean", C.POINTER(C.c_double)),
+        ("argmax_mean", C.POINTER(C.c_double)),
+    ]
+
+
 class GpirtOutputs(C.Structure):
     _fields_ = [
         ("theta", C.POINTER(C.c_double)),

@@ -79,6 +79,11 @@ int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int round);
 int launch_grid_onehot(hipStream_t st, const int8_t *yT, int n, int mloc, int ML, int C, double *oh);
 int launch_grid_table(hipStream_t st, const ThetaArgs &a, int G_pad, double *T);
 int launch_grid_pick(hipStream_t st, const ThetaArgs &a, const double *lp, int G_pad);
+// running sums for the posterior summaries: theta and theta^2; per (unit, grid point) the
+// category probabilities psum[u + U_pad*(c + C*g)] and the most probable category
+// asum[u + U_pad*g], from F* = Gt + beta0 + beta1 x (+ beta2 x^2)
+int launch_summary_theta(hipStream_t st, const double *theta, int64_t count, double *sum, double *sq);
+int launch_summary_prob(hipStream_t st, const ThetaArgs &a, int quadratic, double *psum, double *asum);
 // f[r + ld*u] = Gt[u + U_pad * idx(x_p[r])]   (main.m:69-73)
 int launch_snap(hipStream_t st, const double *Gt, int U_pad, const double *x, int64_t x_stride,
                 int Np, int P, int mloc, int ML, int G, double lo, double step, double *f,

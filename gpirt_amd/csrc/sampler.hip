@@ -103,6 +103,8 @@ struct gpirt_sampler {
   double *d_xc, *d_tnu, *d_prop, *d_hh, *d_phi, *d_pmin, *d_pmax, *d_buf, *d_Lt, *d_tpm, *d_tps;
   double *d_llu;
   double *d_onehot, *d_T, *d_lp;   // static (grid) respondent step only
+  double *d_sum_th, *d_sum_th2, *d_sum_p, *d_sum_arg;   // running sums of the summaries (lazy)
+  int summary_draws;
   int32_t *d_done, *d_info, *d_remaining;
   unsigned long long *d_counters;  // [3][2]: f, param, theta x (evaluations, capped)
   int64_t theta_rounds;
@@ -120,7 +122,8 @@ static void sampler_free(gpirt_sampler *s) {
                   s->d_Gt, s->d_ebeta, s->d_delta, s->d_beta, s->d_bthr, s->d_betaS, s->d_bthrS,
                   s->d_bpm, s->d_bps, s->d_xc, s->d_tnu, s->d_prop, s->d_hh, s->d_phi, s->d_pmin,
                   s->d_pmax, s->d_buf, s->d_Lt, s->d_tpm, s->d_tps, s->d_llu, s->d_done, s->d_info,
-                  s->d_remaining, s->d_counters, s->d_onehot, s->d_T, s->d_lp};
+                  s->d_remaining, s->d_counters, s->d_onehot, s->d_T, s->d_lp,
+                  s->d_sum_th, s->d_sum_th2, s->d_sum_p, s->d_sum_arg};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
   if (s->ev_col) (void)hipEventDestroy(s->ev_col);
@@ -676,6 +679,70 @@ int gpirt_sampler_diagnostics(gpirt_sampler *s, gpirt_outputs *o) {
   return GPIRT_OK;
 }
 
+int gpirt_sampler_accumulate(gpirt_sampler *s, int32_t quadratic) {
+  if (!s) { set_error("sampler is NULL"); return GPIRT_ERR_BAD_ARG; }
+  GP_HIP(hipSetDevice(s->device));
+  if (!s->d_sum_th) {
+    GP_TRY(dalloc(s->d_sum_th, (size_t)s->n * s->H));
+    GP_TRY(dalloc(s->d_sum_th2, (size_t)s->n * s->H));
+    GP_TRY(dalloc(s->d_sum_p, (size_t)s->U_pad * s->C * s->G));
+    GP_TRY(dalloc(s->d_sum_arg, (size_t)s->U_pad * s->G));
+  }
+  GP_TRY(launch_summary_theta(s->st, s->d_theta, (int64_t)s->n * s->H, s->d_sum_th, s->d_sum_th2));
+  ThetaArgs a = theta_args(s);
+  GP_TRY(launch_summary_prob(s->st, a, quadratic != 0, s->d_sum_p, s->d_sum_arg));
+  GP_HIP(hipStreamSynchronize(s->st));
+  s->summary_draws++;
+  return GPIRT_OK;
+}
+
+int gpirt_sampler_summary(gpirt_sampler *s, gpirt_summary *out) {
+  if (!s || !out) { set_error("sampler/out is NULL"); return GPIRT_ERR_BAD_ARG; }
+  if (out->struct_size != (int32_t)sizeof(gpirt_summary)) {
+    set_error("gpirt_summary.struct_size %d != %zu (header mismatch)", out->struct_size, sizeof(gpirt_summary));
+    return GPIRT_ERR_BAD_ARG;
+  }
+  GP_HIP(hipSetDevice(s->device));
+  const int K = s->summary_draws;
+  out->draws = K;
+  if (K < 1) { set_error("no draw has been accumulated"); return GPIRT_ERR_BAD_ARG; }
+  const size_t nH = (size_t)s->n * s->H;
+  if (out->theta_mean || out->theta_sd) {
+    std::vector<double> a(nH), b(nH);
+    GP_HIP(hipMemcpy(a.data(), s->d_sum_th, sizeof(double) * nH, hipMemcpyDeviceToHost));
+    GP_HIP(hipMemcpy(b.data(), s->d_sum_th2, sizeof(double) * nH, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nH; ++i) {
+      const double mean = a[i] / K;
+      if (out->theta_mean) out->theta_mean[i] = mean;
+      if (out->theta_sd) {
+        const double var = K > 1 ? (b[i] - K * mean * mean) / (K - 1) : NAN;   // R's sd(): n-1
+        out->theta_sd[i] = K > 1 ? sqrt(var > 0.0 ? var : 0.0) : NAN;
+      }
+    }
+  }
+  const int G = s->G, C = s->C, P = s->P, mloc = s->mloc, ML = s->ML, U_pad = s->U_pad;
+  if (out->prob_mean) {
+    std::vector<double> h((size_t)U_pad * C * G);
+    GP_HIP(hipMemcpy(h.data(), s->d_sum_p, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (int c = 0; c < C; ++c)
+      for (int p = 0; p < P; ++p)
+        for (int jl = 0; jl < mloc; ++jl)
+          for (int g = 0; g < G; ++g)
+            out->prob_mean[g + (size_t)G * (jl + (size_t)mloc * (p + (size_t)P * c))] =
+                h[(size_t)(jl + ML * p) + (size_t)U_pad * (c + (size_t)C * g)] / K;
+  }
+  if (out->argmax_mean) {
+    std::vector<double> h((size_t)U_pad * G);
+    GP_HIP(hipMemcpy(h.data(), s->d_sum_arg, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (int p = 0; p < P; ++p)
+      for (int jl = 0; jl < mloc; ++jl)
+        for (int g = 0; g < G; ++g)
+          out->argmax_mean[g + (size_t)G * (jl + (size_t)mloc * p)] =
+              h[(size_t)(jl + ML * p) + (size_t)U_pad * g] / K;
+  }
+  return GPIRT_OK;
+}
+
 void *gpirt_sampler_stream(gpirt_sampler *s) { return s ? (void *)s->st : nullptr; }
 
 void gpirt_sampler_destroy(gpirt_sampler *s) {
@@ -710,6 +777,13 @@ static int sampler_loglik(gpirt_sampler *s, double *out) {
 int gpirt_run(const gpirt_config *cfg, const int8_t *y, const double *theta_init,
               const double *bpm, const double *bps, const double *tpm, const double *tps,
               const double *thresholds, gpirt_outputs *out) {
+  return gpirt_run_summary(cfg, y, theta_init, bpm, bps, tpm, tps, thresholds, out, nullptr, 0);
+}
+
+int gpirt_run_summary(const gpirt_config *cfg, const int8_t *y, const double *theta_init,
+                      const double *bpm, const double *bps, const double *tpm, const double *tps,
+                      const double *thresholds, gpirt_outputs *out, gpirt_summary *summary,
+                      int32_t quadratic) {
   gpirt_sampler *s = nullptr;
   GP_TRY(gpirt_sampler_create(cfg, y, theta_init, bpm, bps, tpm, tps, thresholds, &s));
   const int total = cfg->burn_iterations + cfg->sample_iterations;
@@ -725,20 +799,23 @@ int gpirt_run(const gpirt_config *cfg, const int8_t *y, const double *theta_init
     if (rc) break;
     if (out && out->loglik) rc = sampler_loglik(s, &out->loglik[it]);
     if (rc) break;
-    int post = it - cfg->burn_iterations;
-    if (out && post >= 0 && (post + 1) % thin == 0 && k < K) {
+    const int post = it - cfg->burn_iterations;
+    const bool keep = post >= 0 && (post + 1) % thin == 0 && k < K;
+    if (out && keep) {
       rc = gpirt_sampler_get_state(
           s, out->theta ? out->theta + nH * k : nullptr,
           (out->f && (cfg->flags & GPIRT_RETURN_F)) ? out->f + sf * k : nullptr,
           (out->fstar && (cfg->flags & GPIRT_RETURN_FSTAR)) ? out->fstar + sfs * k : nullptr,
           out->beta ? out->beta + sb * k : nullptr, out->threshold ? out->threshold + stt * k : nullptr);
-      ++k;
     }
+    if (!rc && summary && keep) rc = gpirt_sampler_accumulate(s, quadratic);
+    if (keep) ++k;
     if (!rc && cfg->progress && cfg->progress(it + 1, total, cfg->progress_user)) {
       set_error("interrupted by the progress callback at sweep %d", it + 1);
       rc = GPIRT_ERR_INTERRUPT;
     }
   }
+  if (!rc && summary) rc = gpirt_sampler_summary(s, summary);
   if (out) {
     int rc2 = gpirt_sampler_diagnostics(s, out);
     if (!rc) rc = rc2;

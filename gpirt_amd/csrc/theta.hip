@@ -251,6 +251,57 @@ int launch_grid_pick(hipStream_t st, const ThetaArgs &a, const double *lp, int G
 }
 
 // ---------------------------------------------------------------------------------------
+// Running sums for the posterior summaries (gpirt-sythetic.R:111-133,151-214; the table
+// behind getprobs_gpirt, getprob_gpirt.R:1-20)
+// ---------------------------------------------------------------------------------------
+__global__ void summary_theta_kernel(const double *__restrict__ theta, int64_t count,
+                                     double *__restrict__ sum, double *__restrict__ sq) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const double t = theta[i];
+  sum[i] += t;
+  sq[i] += t * t;
+}
+
+int launch_summary_theta(hipStream_t st, const double *theta, int64_t count, double *sum, double *sq) {
+  hipLaunchKernelGGL(summary_theta_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, theta,
+                     count, sum, sq);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+__global__ __launch_bounds__(256) void summary_prob_kernel(ThetaArgs a, int quadratic,
+                                                           double *__restrict__ psum,
+                                                           double *__restrict__ asum) {
+  __shared__ double sphi[PHI_LDS_DOUBLES];
+  phi_table_to_lds(sphi);
+  __syncthreads();
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+  const int U_pad = a.U_pad;
+  if (u >= U_pad || u % a.ML >= a.mloc) return;
+  const double xg = a.grid_lo + a.grid_step * g;
+  double F = a.Gt[u + (int64_t)U_pad * g] + a.betaS[u] + a.betaS[u + U_pad] * xg;
+  if (quadratic) F += a.betaS[u + 2 * (int64_t)U_pad] * xg * xg;
+  double lo = a.bthrS[u], best = -1.0;
+  int arg = 1;
+  for (int c = 0; c < a.C; ++c) {
+    const double hi = a.bthrS[u + (int64_t)U_pad * (c + 1)];
+    const double p = ordinal_cell_prob(lo - F, hi - F, sphi);
+    psum[u + (int64_t)U_pad * (c + (int64_t)a.C * g)] += p;
+    if (p > best) { best = p; arg = c + 1; }      // which.max: the first maximum
+    lo = hi;
+  }
+  asum[u + (int64_t)U_pad * g] += (double)arg;
+}
+
+int launch_summary_prob(hipStream_t st, const ThetaArgs &a, int quadratic, double *psum, double *asum) {
+  hipLaunchKernelGGL(summary_prob_kernel, dim3((a.U_pad + 255) / 256, a.G), dim3(256), 0, st, a,
+                     quadratic, psum, asum);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // snap: re-anchor f at the new theta from f* (main.m:69-73).  Gt is unit-contiguous, f is
 // row-contiguous: a 64x64 tile goes through LDS so that both sides are coalesced.
 // ---------------------------------------------------------------------------------------

@@ -41,7 +41,7 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, THIN=1, CHAIN=1,
               vote_codes=None, thresholds=None, SEED=1, constant_IRF=0, KERNEL="RBF",
               beta_proposal_sds=None, *, return_f=True, return_fstar=True, theta_mode="ess",
               jitter=1e-6, max_ess_rounds=200, item_range=None, rank=0, world=1, allreduce=None,
-              progress=None):
+              progress=None, summary=False, summary_quadratic=False):
     """Run ``CHAIN`` independent chains; returns a list with one dict per chain holding
 
     ``theta [K, n, H]``, ``f [K, n, m, H]``, ``fstar [K, 1001, m, H]``, ``beta [K, 3, m, H]``,
@@ -49,7 +49,9 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, THIN=1, CHAIN=1,
     ``samples["fstar"][it][:, j, h]`` reads like the R list ``samples$fstar[[it]][, j, h]``.
     ``f``/``fstar`` exclude the linear part ``beta[0] + beta[1]*theta`` as in the reference
     (gpirt-sythetic.R:153-154).  ``vote_codes`` and ``beta_proposal_sds`` are accepted and
-    ignored (legacy arguments, gpirt_CIRI.R:135).
+    ignored (legacy arguments, gpirt_CIRI.R:135).  ``summary=True`` adds ``"summary"``: the
+    posterior summaries accumulated on the device (``gpirt_amd.post`` turns them into the
+    reference's evaluation metrics), so that ``return_f`` / ``return_fstar`` can be False.
     """
     del vote_codes, beta_proposal_sds
     y = responses_from_r(data)
@@ -108,7 +110,13 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, THIN=1, CHAIN=1,
             out.f = ff.ctypes.data_as(_dp)
         if fs is not None:
             out.fstar = fs.ctypes.data_as(_dp)
-        check(lib().gpirt_run(C.byref(cfg), *inp.args(), C.byref(out)))
+        summ = None
+        if summary:
+            from .sampler import fetch_summary
+            summ = fetch_summary(cfg, lambda sm: check(lib().gpirt_run_summary(
+                C.byref(cfg), *inp.args(), C.byref(out), C.byref(sm), int(bool(summary_quadratic)))))
+        else:
+            check(lib().gpirt_run(C.byref(cfg), *inp.args(), C.byref(out)))
 
         def per_period(a):  # [.., P, K] -> [K, .., H]
             a = np.moveaxis(a, -1, 0)
@@ -123,6 +131,7 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, THIN=1, CHAIN=1,
             beta=per_period(be),
             threshold=per_period(tr),
             loglik=ll,
+            summary=summ,
             diagnostics=dict(ess_f_rounds=out.ess_f_rounds, ess_param_rounds=out.ess_param_rounds,
                              ess_theta_rounds=out.ess_theta_rounds, ess_capped=out.ess_capped,
                              jitter_retries=out.jitter_retries, seconds=out.seconds_total),

@@ -54,6 +54,20 @@ class HostInputs:
                 _d(self.tpm), _d(self.tps), _d(self.thr))
 
 
+def fetch_summary(cfg, call):
+    """Allocate the buffers of a ``gpirt_summary``, let `call(summary)` fill them, return a dict."""
+    mloc, P = local_shape(cfg)
+    sm = _abi.GpirtSummary()
+    sm.struct_size = C.sizeof(_abi.GpirtSummary)
+    tm = np.empty((cfg.n, cfg.H), order="F")
+    ts = np.empty((cfg.n, cfg.H), order="F")
+    pm = np.empty((cfg.n_grid, mloc, P, cfg.C), order="F")
+    am = np.empty((cfg.n_grid, mloc, P), order="F")
+    sm.theta_mean, sm.theta_sd, sm.prob_mean, sm.argmax_mean = _d(tm), _d(ts), _d(pm), _d(am)
+    call(sm)
+    return dict(theta_mean=tm, theta_sd=ts, prob_mean=pm, argmax_mean=am, draws=int(sm.draws))
+
+
 class Sampler:
     def __init__(self, cfg, y, **inputs):
         self.cfg = cfg
@@ -87,6 +101,15 @@ class Sampler:
         return dict(ess_f_rounds=o.ess_f_rounds, ess_param_rounds=o.ess_param_rounds,
                     ess_theta_rounds=o.ess_theta_rounds, ess_capped=o.ess_capped,
                     jitter_retries=o.jitter_retries)
+
+    def accumulate(self, quadratic=False):
+        """Add the current state to the device-side running sums of the posterior summaries."""
+        check(lib().gpirt_sampler_accumulate(self._h, int(bool(quadratic))))
+
+    def summary(self):
+        """``theta_mean/theta_sd [n,H]``, ``prob_mean [n_grid,m_loc,P,C]``,
+        ``argmax_mean [n_grid,m_loc,P]`` over the draws accumulated so far."""
+        return fetch_summary(self.cfg, lambda sm: check(lib().gpirt_sampler_summary(self._h, C.byref(sm))))
 
     def stream(self):
         return lib().gpirt_sampler_stream(self._h)

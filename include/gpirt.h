@@ -194,6 +194,39 @@ int gpirt_sampler_get_state(gpirt_sampler *s, double *theta, double *f, double *
 int gpirt_sampler_phase_times(gpirt_sampler *s, double *ms, int64_t *count);
 /* Diagnostics so far: fills the counters of `out` (buffers untouched). */
 int gpirt_sampler_diagnostics(gpirt_sampler *s, gpirt_outputs *out);
+/* ---- posterior summaries from running sums on the device ---------------------------
+ * What the reference's R post-processing derives from the kept draws
+ * (gpirt-sythetic.R:111-133,151-214,231-251; getprob_gpirt.R:1-20), accumulated on the
+ * device so that the f / f* draws need not leave it:
+ *   theta_mean, theta_sd   pred_theta / pred_theta_sd before centring (:122-123), sd with
+ *                          the n-1 divisor of R's sd()
+ *   prob_mean              mean over draws of P(y = c | x_g) =
+ *                          Phi(b_c - F*(x_g)) - Phi(b_{c-1} - F*(x_g)) with
+ *                          F* = fstar + beta_0 + beta_1 x_g (:153-154; `quadratic` adds
+ *                          beta_2 x_g^2, which the reference's post-processing leaves out):
+ *                          the table behind getprobs_gpirt's ICC and the predictive
+ *                          log-likelihood at any grid index
+ *   argmax_mean            mean over draws of which.max_c of that probability (:197,208)
+ * Buffers are caller-allocated; any pointer may be NULL. */
+typedef struct gpirt_summary {
+  int32_t struct_size;  /* = sizeof(gpirt_summary)                                  */
+  int32_t draws;        /* out: number of accumulated draws                         */
+  double *theta_mean;   /* [n, H]                                                   */
+  double *theta_sd;     /* [n, H]                                                   */
+  double *prob_mean;    /* [n_grid, m_loc, P, C]                                    */
+  double *argmax_mean;  /* [n_grid, m_loc, P]   (categories counted from 1)         */
+} gpirt_summary;
+/* Add the sampler's current state to the running sums (call after a kept sweep). */
+int gpirt_sampler_accumulate(gpirt_sampler *s, int32_t quadratic);
+/* Finish the running sums into `out` (they keep accumulating afterwards). */
+int gpirt_sampler_summary(gpirt_sampler *s, gpirt_summary *out);
+/* gpirt_run that also accumulates every kept draw; `summary` may be NULL. */
+int gpirt_run_summary(const gpirt_config *cfg, const int8_t *y, const double *theta_init,
+                      const double *beta_prior_means, const double *beta_prior_sds,
+                      const double *theta_prior_means, const double *theta_prior_sds,
+                      const double *thresholds, gpirt_outputs *out, gpirt_summary *summary,
+                      int32_t quadratic);
+
 /* The HIP stream every kernel of this sampler is launched on (as a void*). */
 void *gpirt_sampler_stream(gpirt_sampler *s);
 void gpirt_sampler_destroy(gpirt_sampler *s);

@@ -278,3 +278,29 @@ def test_gpirtmcmc_drop_in_recovers_theta():
     est_c = cpu["theta"].mean(axis=2)
     assert np.corrcoef(est.ravel(), est_c.ravel())[0, 1] > 0.99
     assert res["diagnostics"]["ess_capped"] == 0
+
+
+@pytest.mark.parametrize("const,quad", [(0, False), (1, True)])
+def test_device_summaries_match_the_kept_draws(const, quad):
+    """The running sums kept on the device (theta mean / sd, category probabilities and most
+    probable category on the grid: gpirt-sythetic.R:111-133,151-214) against the same
+    quantities computed from the returned draws."""
+    from gpirt_amd import post
+    from gpirt_amd.mcmc import gpirtMCMC
+    d = load_fixture("Wiener_C_5")
+    H = 3
+    y, theta = d["y_train"][:, :, :H], d["theta"][:, :H]
+    ch = gpirtMCMC(y, 24, 8, THIN=4, theta_os=1.0, theta_ls=1.5, theta_init=theta, SEED=3,
+                   constant_IRF=const, summary=True, summary_quadratic=quad)[0]
+    sm = ch["summary"]
+    ref = post.summarize_draws(ch, quadratic=quad)
+    assert sm["draws"] == 6 == ref["draws"]
+    assert np.abs(sm["theta_mean"] - ref["theta_mean"]).max() < 1e-12
+    assert np.abs(sm["theta_sd"] - ref["theta_sd"]).max() < 1e-10
+    P = 1 if const else H
+    assert sm["prob_mean"].shape == (1001, y.shape[1], P, 5)
+    assert np.abs(sm["prob_mean"] - ref["prob_mean"][:, :, :P]).max() < 1e-12
+    assert np.abs(sm["argmax_mean"] - ref["argmax_mean"][:, :, :P]).max() < 1e-12
+    ev = post.evaluate(sm, d["y"][:, :, :H], d["train_idx"][:, :, :H], theta)
+    if not const:        # the fixture was generated with period-specific response functions
+        assert ev["mean_abs_cor_theta"] > 0.9
