@@ -34,3 +34,50 @@ for stem in ("2PL_C_2_n_100_m_10_h_10_CSTIRF_0_SEED_1",
             keep[k] = d[k]
     np.savez_compressed(os.path.join(OUT, stem + ".npz"), **keep)
     print(stem, {k: getattr(v, "shape", None) for k, v in keep.items()})
+
+
+# ---- builders: a cut of the Voteview inputs with the matching cut of the reference's own
+# stored cube (data/senate_data_90.RData, written by senatedata.R:71), and a cut of the TAPS
+# long file -------------------------------------------------------------------------------
+import csv  # noqa: E402
+
+
+def _cols(path, names):
+    out = {k: [] for k in names}
+    with open(path, newline="") as fh:
+        for row in csv.DictReader(fh):
+            for k in names:
+                out[k].append(row[k])
+    return out
+
+
+ROLL_MAX = 40
+mini = {}
+for sid in (90, 91):
+    v = _cols(os.path.join(REF, "data", "S%d_votes.csv" % sid), ("icpsr", "rollnumber", "cast_code"))
+    keep = [i for i, r in enumerate(v["rollnumber"]) if int(float(r)) <= ROLL_MAX]
+    for k in v:
+        mini["S%d_votes_%s" % (sid, k)] = np.array([int(float(v[k][i])) for i in keep], dtype=np.int32)
+    r = _cols(os.path.join(REF, "data", "S%d_rollcalls.csv" % sid), ("rollnumber", "yea_count", "nay_count"))
+    keep = [i for i, x in enumerate(r["rollnumber"]) if int(float(x)) <= ROLL_MAX]
+    for k in r:
+        mini["S%d_rollcalls_%s" % (sid, k)] = np.array([int(float(r[k][i])) for i in keep], dtype=np.int32)
+stored = read_rdata(os.path.join(REF, "data", "senate_data_90.RData"))
+mini["stored_cube"] = np.asfortranarray(responses_to_int8(stored["data"])[:, :ROLL_MAX, :2])
+mini["stored_icpsr"] = np.asarray(stored["unique_icpsr"]).astype(np.int32)
+np.savez_compressed(os.path.join(OUT, "senate_mini.npz"), **mini)
+print("senate_mini", {k: v.shape for k, v in mini.items()})
+
+t = _cols(os.path.join(REF, "TAPS", "TAPS-econ-data-long.csv"),
+          ("WUSTLID", "wave", "ECON2A", "ECON2B", "ECON1A", "ECON1B", "ECON4A", "ECON4B"))
+first_ids = []
+for w in t["WUSTLID"]:
+    if w not in first_ids:
+        first_ids.append(w)
+    if len(first_ids) == 40:
+        break
+keep = [i for i, w in enumerate(t["WUSTLID"]) if w in first_ids]
+taps = {k: np.array([-1 if t[k][i] in ("NA", "") else int(float(t[k][i])) for i in keep], dtype=np.int32)
+        for k in t}
+np.savez_compressed(os.path.join(OUT, "taps_mini.npz"), **taps)
+print("taps_mini", {k: v.shape for k, v in taps.items()})
