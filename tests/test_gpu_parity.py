@@ -1,5 +1,7 @@
 """GPU parity: every deterministic device kernel, called through the C ABI, against the CPU
 oracle on the same seeded inputs (tolerances stated per test), then the full sweep."""
+import os
+
 import numpy as np
 import pytest
 
@@ -304,3 +306,21 @@ def test_device_summaries_match_the_kept_draws(const, quad):
     ev = post.evaluate(sm, d["y"][:, :, :H], d["train_idx"][:, :, :H], theta)
     if not const:        # the fixture was generated with period-specific response functions
         assert ev["mean_abs_cor_theta"] > 0.9
+
+
+def test_config_c_senate_116_recovers_the_nominate_ordering():
+    """BASELINE config C end to end: the 116th Senate roll-call cube (103 x 703, binary,
+    built by gpirt_amd.builders.senate_cube) through the gpirtMCMC mirror from a random start;
+    the posterior mean of theta must order the senators like NOMINATE's first dimension
+    (the comparison of gpirt-senate.R:86-127)."""
+    from gpirt_amd import post
+    from gpirt_amd.mcmc import gpirtMCMC
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "senate_116.npz"))
+    data, nom = d["data"], d["nominate_dim1"]
+    ch = gpirtMCMC(data, 80, 80, THIN=4, beta_prior_sds=np.ones((2, data.shape[1])), theta_os=1.0,
+                   theta_ls=10.0, SEED=1, return_f=False, return_fstar=False, summary=True)[0]
+    ok = np.isfinite(nom)
+    theta = ch["summary"]["theta_mean"][:, 0]
+    assert abs(np.corrcoef(theta[ok], nom[ok])[0, 1]) > 0.9
+    ev = post.evaluate(ch["summary"], data)
+    assert ev["train_acc"] > 0.85                      # roll calls are well predicted by one dimension
