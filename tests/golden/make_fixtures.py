@@ -98,3 +98,12 @@ nom = np.array([score.get(int(k), np.nan) for k in c["icpsr"]])
 np.savez_compressed(os.path.join(OUT, "senate_116.npz"), data=c["data"], icpsr=c["icpsr"].astype(np.int32),
                     nominate_dim1=nom)
 print("senate_116", c["data"].shape, int(np.isfinite(nom).sum()))
+
+
+# ---- BASELINE config D: the TAPS panel cube (TAPS/load_TAPS.R) ------------------------------
+from gpirt_amd.builders import taps_cube  # noqa: E402
+
+t = taps_cube(os.path.join(REF, "TAPS", "TAPS-econ-data-long.csv"))
+np.savez_compressed(os.path.join(OUT, "taps_cube.npz"), data=t["data"], ids=t["ids"].astype(np.int64),
+                    waves=t["waves"].astype(np.int32))
+print("taps_cube", t["data"].shape)
