@@ -32,6 +32,9 @@ SYMBOLS = {
     "gpirt_sampler_summary": (C.c_int, [C.c_void_p, C.POINTER(_abi.GpirtSummary)]),
     "gpirt_run_summary": (C.c_int, [C.POINTER(_abi.GpirtConfig), _bp, _dp, _dp, _dp, _dp, _dp, _dp,
                                     C.POINTER(_abi.GpirtOutputs), C.POINTER(_abi.GpirtSummary), C.c_int32]),
+    "gpirt_sampler_checkpoint_bytes": (C.c_int64, [C.c_void_p]),
+    "gpirt_sampler_checkpoint": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "gpirt_sampler_restore": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "gpirt_sampler_stream": (C.c_void_p, [C.c_void_p]),
     "gpirt_sampler_destroy": (None, [C.c_void_p]),
     "gpirt_k_build": (C.c_int, [_dp, C.c_int32, C.c_double, C.c_double, C.c_double, _dp]),

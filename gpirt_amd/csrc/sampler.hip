@@ -679,6 +679,101 @@ int gpirt_sampler_diagnostics(gpirt_sampler *s, gpirt_outputs *o) {
   return GPIRT_OK;
 }
 
+// ---- checkpoint / resume ----------------------------------------------------------------
+namespace {
+struct CkptHeader {
+  uint64_t magic;
+  int32_t n, m, H, C, P, mloc, j0, G;
+  uint64_t seed;
+  uint32_t sweep;
+  int32_t jitter_retries;
+  double jitter_now;
+  int64_t theta_rounds;
+  unsigned long long counters[6];
+};
+constexpr uint64_t kCkptMagic = 0x3154504b43525047ull;   // "GPRCKPT1"
+
+struct CkptPart { void *dev; size_t bytes; };
+void ckpt_parts(gpirt_sampler *s, std::vector<CkptPart> &parts) {
+  const size_t U = s->U_pad, C = s->C;
+  parts = {
+      {s->d_theta, sizeof(double) * (size_t)s->n * s->H},
+      {s->d_f, sizeof(double) * (size_t)s->Np_pad * U},
+      {s->d_Gt, sizeof(double) * U * s->G_pad},
+      {s->d_ebeta, sizeof(double) * 3 * U},
+      {s->d_delta, sizeof(double) * (C - 1) * U},
+      {s->d_beta, sizeof(double) * 3 * U},
+      {s->d_bthr, sizeof(double) * (C + 1) * U},
+      {s->d_betaS, sizeof(double) * 3 * U},
+      {s->d_bthrS, sizeof(double) * (C + 1) * U},
+  };
+}
+}  // namespace
+
+int64_t gpirt_sampler_checkpoint_bytes(gpirt_sampler *s) {
+  if (!s) return 0;
+  size_t total = sizeof(CkptHeader);
+  std::vector<CkptPart> parts;
+  ckpt_parts(s, parts);
+  for (const CkptPart &p : parts) total += p.bytes;
+  return (int64_t)total;
+}
+
+int gpirt_sampler_checkpoint(gpirt_sampler *s, void *blob, int64_t bytes) {
+  if (!s || !blob) { set_error("sampler/blob is NULL"); return GPIRT_ERR_BAD_ARG; }
+  if (bytes < gpirt_sampler_checkpoint_bytes(s)) {
+    set_error("checkpoint buffer too small: %lld < %lld", (long long)bytes,
+              (long long)gpirt_sampler_checkpoint_bytes(s));
+    return GPIRT_ERR_BAD_ARG;
+  }
+  GP_HIP(hipSetDevice(s->device));
+  GP_HIP(hipStreamSynchronize(s->st));
+  CkptHeader h{};
+  h.magic = kCkptMagic;
+  h.n = s->n; h.m = s->m; h.H = s->H; h.C = s->C; h.P = s->P; h.mloc = s->mloc; h.j0 = s->j0; h.G = s->G;
+  h.seed = s->seed; h.sweep = s->sweep; h.jitter_retries = s->jitter_retries;
+  h.jitter_now = s->jitter_now; h.theta_rounds = s->theta_rounds;
+  GP_HIP(hipMemcpy(h.counters, s->d_counters, sizeof h.counters, hipMemcpyDeviceToHost));
+  char *out = static_cast<char *>(blob);
+  memcpy(out, &h, sizeof h);
+  out += sizeof h;
+  std::vector<CkptPart> parts;
+  ckpt_parts(s, parts);
+  for (const CkptPart &p : parts) {
+    GP_HIP(hipMemcpy(out, p.dev, p.bytes, hipMemcpyDeviceToHost));
+    out += p.bytes;
+  }
+  return GPIRT_OK;
+}
+
+int gpirt_sampler_restore(gpirt_sampler *s, const void *blob, int64_t bytes) {
+  if (!s || !blob) { set_error("sampler/blob is NULL"); return GPIRT_ERR_BAD_ARG; }
+  if (bytes < gpirt_sampler_checkpoint_bytes(s)) {
+    set_error("checkpoint blob too small for this sampler");
+    return GPIRT_ERR_BAD_ARG;
+  }
+  CkptHeader h;
+  memcpy(&h, blob, sizeof h);
+  if (h.magic != kCkptMagic || h.n != s->n || h.m != s->m || h.H != s->H || h.C != s->C || h.P != s->P ||
+      h.mloc != s->mloc || h.j0 != s->j0 || h.G != s->G || h.seed != s->seed) {
+    set_error("checkpoint does not belong to a sampler of this shape, item range and seed");
+    return GPIRT_ERR_BAD_ARG;
+  }
+  GP_HIP(hipSetDevice(s->device));
+  GP_HIP(hipStreamSynchronize(s->st));
+  const char *in = static_cast<const char *>(blob) + sizeof h;
+  std::vector<CkptPart> parts;
+  ckpt_parts(s, parts);
+  for (const CkptPart &p : parts) {
+    GP_HIP(hipMemcpy(p.dev, in, p.bytes, hipMemcpyHostToDevice));
+    in += p.bytes;
+  }
+  GP_HIP(hipMemcpy(s->d_counters, h.counters, sizeof h.counters, hipMemcpyHostToDevice));
+  s->sweep = h.sweep; s->jitter_retries = h.jitter_retries; s->jitter_now = h.jitter_now;
+  s->theta_rounds = h.theta_rounds;
+  return GPIRT_OK;
+}
+
 int gpirt_sampler_accumulate(gpirt_sampler *s, int32_t quadratic) {
   if (!s) { set_error("sampler is NULL"); return GPIRT_ERR_BAD_ARG; }
   GP_HIP(hipSetDevice(s->device));

@@ -111,6 +111,18 @@ class Sampler:
         ``argmax_mean [n_grid,m_loc,P]`` over the draws accumulated so far."""
         return fetch_summary(self.cfg, lambda sm: check(lib().gpirt_sampler_summary(self._h, C.byref(sm))))
 
+    def checkpoint(self):
+        """The chain's state as bytes; `restore` into a sampler built from the same
+        configuration and data continues the chain bit for bit."""
+        size = int(lib().gpirt_sampler_checkpoint_bytes(self._h))
+        buf = np.empty(size, dtype=np.uint8)
+        check(lib().gpirt_sampler_checkpoint(self._h, buf.ctypes.data_as(C.c_void_p), size))
+        return buf.tobytes()
+
+    def restore(self, blob):
+        buf = np.frombuffer(blob, dtype=np.uint8)
+        check(lib().gpirt_sampler_restore(self._h, buf.ctypes.data_as(C.c_void_p), int(buf.size)))
+
     def stream(self):
         return lib().gpirt_sampler_stream(self._h)
 

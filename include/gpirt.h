@@ -227,6 +227,16 @@ int gpirt_run_summary(const gpirt_config *cfg, const int8_t *y, const double *th
                       const double *thresholds, gpirt_outputs *out, gpirt_summary *summary,
                       int32_t quadratic);
 
+/* ---- checkpoint / resume --------------------------------------------------------------
+ * Everything a chain needs to continue exactly where it stopped (theta, f, f*, the
+ * whitened beta / threshold parameters and their derived copies, the sweep counter that keys
+ * the random streams, the current jitter, the diagnostics counters) as one opaque host
+ * blob.  Restoring it into a sampler created with the SAME configuration and data continues
+ * the chain bit for bit.  The running sums of the summaries are not part of it. */
+int64_t gpirt_sampler_checkpoint_bytes(gpirt_sampler *s);
+int gpirt_sampler_checkpoint(gpirt_sampler *s, void *blob, int64_t bytes);
+int gpirt_sampler_restore(gpirt_sampler *s, const void *blob, int64_t bytes);
+
 /* The HIP stream every kernel of this sampler is launched on (as a void*). */
 void *gpirt_sampler_stream(gpirt_sampler *s);
 void gpirt_sampler_destroy(gpirt_sampler *s);

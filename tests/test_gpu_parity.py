@@ -324,3 +324,29 @@ def test_config_c_senate_116_recovers_the_nominate_ordering():
     assert abs(np.corrcoef(theta[ok], nom[ok])[0, 1]) > 0.9
     ev = post.evaluate(ch["summary"], data)
     assert ev["train_acc"] > 0.85                      # roll calls are well predicted by one dimension
+
+
+def test_checkpoint_restore_continues_the_chain_bit_for_bit():
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd._lib import GpirtError
+    d = load_fixture("Wiener_C_5")
+    y, theta = d["y"][:, :, :3], d["theta"][:, :3]
+    n, m, H = y.shape
+    cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=21, theta_ls=1.5)
+    a = Sampler(cfg, y, theta_init=theta)
+    a.sweep(3)
+    blob = a.checkpoint()
+    a.sweep(3)
+    want, want_diag = a.state(), a.diagnostics()
+    a.close()
+    b = Sampler(cfg, y, theta_init=np.zeros_like(theta))      # different start: all of it is overwritten
+    b.restore(blob)
+    b.sweep(3)
+    got = b.state()
+    for k in ("theta", "f", "fstar", "beta"):
+        assert np.array_equal(got[k], want[k]), k
+    assert b.diagnostics() == want_diag
+    other = Sampler(_abi.default_config(n=n, m=m, H=H, C=5, seed=22, theta_ls=1.5), y, theta_init=theta)
+    with pytest.raises(GpirtError):
+        other.restore(blob)                                   # another seed: refused
+    b.close(); other.close()
