@@ -79,7 +79,26 @@ def _cor(a, b):
     return float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
 
 
-def evaluate(summary, data, train_idx=None, theta_true=None, truth=None):
+def holdout_mask(data, periods, drop_percent, seed=0):
+    """train_idx for the k-step-ahead experiments (TAPS/gpirt_TAPS_holdout.R:50-59): in each of
+    `periods` (0-based) and for each item, ``int(drop_percent/100 * n)`` of the answered cells
+    are held out.  Returns int8 [n, m, H], 1 = train, 0 = held out; pass
+    ``np.where(mask == 1, data, 0)`` to the sampler.  (R's own ``sample()`` stream cannot be
+    reproduced here, only its rule.)"""
+    data = np.asarray(data)
+    n, m, H = data.shape
+    rng = np.random.default_rng(seed)
+    mask = np.ones((n, m, H), dtype=np.int8)
+    for h in periods:
+        for j in range(m):
+            answered = np.flatnonzero(data[:, j, h] > 0)
+            k = min(int(drop_percent / 100.0 * n), answered.size)
+            if k > 0:
+                mask[rng.choice(answered, size=k, replace=False), j, h] = 0
+    return mask
+
+
+def evaluate(summary, data, train_idx=None, theta_true=None, truth=None, prediction="mean_argmax"):
     """The reference's evaluation (gpirt-sythetic.R:131-143,187-283) from a summary.
 
     data       int [n, m, H], 1..C, 0 = NA (the FULL data: held-out cells included)
@@ -87,6 +106,9 @@ def evaluate(summary, data, train_idx=None, theta_true=None, truth=None):
     theta_true [n, H] generating abilities (None skips the theta metrics)
     truth      dict with ``thresholds`` and either ``alpha``/``beta`` (2PL) or
                ``anchor_xs``/``anchor_ys``/``SIGMA`` (None skips the ICC metrics)
+    prediction "mean_argmax": round(mean over draws of which.max), gpirt-sythetic.R:197,208;
+               "argmax_mean": which.max of the posterior-mean probabilities, the rule of the
+               hold-out scripts (TAPS/gpirt_TAPS_holdout.R:176-180)
 
     Predictive log-likelihood of a cell: log of the posterior-mean probability of the observed
     category at the respondent's grid index -- the reference's commented-out
@@ -124,7 +146,10 @@ def evaluate(summary, data, train_idx=None, theta_true=None, truth=None):
     gi = idx[ii, hh]
     with np.errstate(divide="ignore"):
         ll_cell = np.log(pm[gi, jj, hh, yy - 1])
-    y_pred = np.rint(am[gi, jj, hh])                                                          # :208
+    if prediction == "mean_argmax":
+        y_pred = np.rint(am[gi, jj, hh])                                                      # :208
+    else:   # "argmax_mean": which.max of the posterior-mean probabilities (gpirt_TAPS_holdout.R:179)
+        y_pred = 1 + np.argmax(pm[gi, jj, hh], axis=-1)
     hit = (y_pred == yy)
     tr = np.ones(ii.size, dtype=bool) if train_idx is None else (np.asarray(train_idx)[ii, jj, hh] != 0)
     for name, mask in (("train", tr), ("pred", ~tr)):
@@ -132,6 +157,11 @@ def evaluate(summary, data, train_idx=None, theta_true=None, truth=None):
         out[name + "_ll"] = float(ll_cell[fin].mean()) if fin.any() else float("nan")
         out[name + "_acc"] = float(hit[fin].mean()) if fin.any() else float("nan")
         out[name + "_cells"] = int(mask.sum())
+        # per period: the k-step-ahead tables of TAPS/gpirt_TAPS_holdout.R:146-199
+        out[name + "_ll_by_period"] = np.array(
+            [ll_cell[fin & (hh == h)].mean() if (fin & (hh == h)).any() else np.nan for h in range(H)])
+        out[name + "_acc_by_period"] = np.array(
+            [hit[fin & (hh == h)].mean() if (fin & (hh == h)).any() else np.nan for h in range(H)])
 
     # item characteristic curves (:230-251): expected category on xs[301:701]
     if truth is not None:

@@ -109,3 +109,21 @@ def test_reference_acceptance_metrics_on_its_fixture_with_the_cpu_chain():
     assert ev["mean_abs_cor_icc"] > 0.8
     assert ev["train_acc"] > 0.3 and ev["pred_acc"] > 0.3      # 5 categories: chance is 0.2
     assert ev["pred_cells"] > 0 and ev["train_cells"] > ev["pred_cells"]
+
+
+def test_holdout_mask_and_per_period_scores():
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 4, size=(40, 3, 5))
+    mask = post.holdout_mask(data, periods=(3, 4), drop_percent=20, seed=1)
+    assert mask[:, :, :3].all()
+    for h in (3, 4):
+        for j in range(3):
+            held = np.flatnonzero(mask[:, j, h] == 0)
+            assert held.size == 8 and (data[held, j, h] > 0).all()
+    s = _fake_draws(K=4, n=40, m=3, H=5, C=3, seed=7)
+    summ = post.summarize_draws(s)
+    ev = post.evaluate(summ, data, mask, prediction="argmax_mean")
+    assert np.isnan(ev["pred_ll_by_period"][:3]).all() and np.isfinite(ev["pred_ll_by_period"][3:]).all()
+    assert ev["pred_cells"] == 48
+    w = np.array([(mask[:, :, h] == 0).sum() for h in (3, 4)])
+    assert abs(ev["pred_ll"] - (ev["pred_ll_by_period"][3:] * w).sum() / w.sum()) < 1e-12
