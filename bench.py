@@ -86,8 +86,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=10000)
-    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--n", "--respondents", dest="n", type=int, default=10000)
+    ap.add_argument("--m", "--items", dest="m", type=int, default=4096)
     ap.add_argument("--C", type=int, default=5)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,6 +101,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    rehearsal = os.environ.get("GPIRT_BENCH_BACKEND") == "gloo"
+    if world > 1:
+        # torch first: it brings its own copy of the HIP runtime, and a process in which
+        # libgpirt_hip.so has already initialised the system's copy finds no GPU from torch
+        import torch
+        if rehearsal:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
+        torch.zeros(1, device="cuda")
 
     from gpirt_amd import _abi, _lib
     from gpirt_amd.dist import item_range, torch_allreduce
@@ -117,12 +127,18 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        # stream-ordered hook: the collective is enqueued on the sampler's own HIP stream, no
-        # host round trip per proposal round (GPIRT_BENCH_SYNC_ALLREDUCE=1: the blocking hook)
-        on_stream = not os.environ.get("GPIRT_BENCH_SYNC_ALLREDUCE")
-        hook = torch_allreduce(device_buffers=True, on_stream=on_stream)
+        if rehearsal:
+            # rehearsal of the multi-rank logic on a box with fewer GPUs than ranks: gloo
+            # carries the exchange through host memory (not a performance configuration)
+            dist.init_process_group(backend="gloo")
+            on_stream = False
+            hook = torch_allreduce(device_buffers=True, via_host=True)
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            # stream-ordered hook: the collective is enqueued on the sampler's own HIP stream,
+            # no host round trip per proposal round (GPIRT_BENCH_SYNC_ALLREDUCE=1: blocking hook)
+            on_stream = not os.environ.get("GPIRT_BENCH_SYNC_ALLREDUCE")
+            hook = torch_allreduce(device_buffers=True, on_stream=on_stream)
 
     n, m, C = args.n, args.m, args.C
     data = generate(n, m, C, seed=args.seed)          # identical on every rank
@@ -160,7 +176,8 @@ def main():
     d1 = s.diagnostics()
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

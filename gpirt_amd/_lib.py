@@ -57,6 +57,11 @@ class GpirtError(RuntimeError):
         self.code = code
 
 
+def loaded():
+    """True once ``libgpirt_hip.so`` is in the process."""
+    return _lib is not None
+
+
 def lib():
     """The loaded ``libgpirt_hip.so``; raises if it has not been built."""
     global _lib

@@ -34,6 +34,13 @@ def torch_allreduce(group=None, device_buffers=True, via_host=False, on_stream=F
     already on the sampler's HIP stream and the hook returns at once -- set
     ``hook.stream_ptr = sampler.stream()`` after creating the sampler and
     ``ALLREDUCE_ON_STREAM`` in ``cfg.flags`` before.  No host round trip per proposal round."""
+    import sys
+    from . import _lib
+    if device_buffers and "torch" not in sys.modules and _lib.loaded():
+        raise RuntimeError(
+            "import torch before the first gpirt_amd call that loads libgpirt_hip.so: torch "
+            "carries its own copy of the HIP runtime and finds no GPU once the system's copy "
+            "has been initialised in the process")
     import torch
     import torch.distributed as dist
 

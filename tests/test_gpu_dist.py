@@ -151,3 +151,25 @@ def test_stream_ordered_rccl_hook_matches_blocking_hook(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_onstream_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     assert open(os.path.join(str(tmp_path), "r.txt")).read() == "ok"
+
+
+def test_bench_runs_with_two_ranks_under_the_launcher(tmp_path):
+    """bench.py exactly as the multi-GPU runs start it (torch.distributed.run, one process per
+    rank), rehearsed on this one-GPU box with both ranks on the same device and gloo carrying
+    the exchange: the multi-rank plumbing (torch before the library, item ranges, the hook,
+    MAX over ranks, one JSON line from rank 0) must work."""
+    import json
+    import subprocess
+    env = dict(os.environ, GPIRT_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--respondents", "300", "--items", "64", "--no-cpu-baseline"]   # (the launcher's own
+    # parser trips over an abbreviated-looking "--n")
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
+    assert out["config"]["items_per_gpu"] == 32
