@@ -162,8 +162,7 @@ inline int64_t potrf_work_elems(int n_pad, int batch) {
 // (inv must be zero-initialised once); *d_info (device int) is set non-zero when a pivot is
 // not positive.
 int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, int *d_info,
-                 double *work, hipStream_t st2 = nullptr, hipEvent_t ev_col = nullptr,
-                 hipEvent_t ev_panel = nullptr);
+                 double *work);
 // B <- S^-1 B (two blocked triangular solves) for `batch` systems sharing the layout;
 // xtmp holds 4 * SUP * nrhs_pad doubles per system (split-K slabs of the diagonal steps).
 int launch_potrs(hipStream_t st, const double *L, const double *inv, int n_pad, int batch,

@@ -340,8 +340,7 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
     tiles = (nsup + 7) / 8 * 8 * 32;
   }
   // few tiles and a depth that is a multiple of the chunk: the low-latency 64x64 variant
-  static const bool no_small = getenv("GPIRT_NO_SMALL_GEMM") != nullptr;
-  if (mode == 0 && !no_small && tiles * a.batch <= SMALL_GEMM_TILES && a.K % SK == 0 && a.K <= 512) {
+  if (mode == 0 && tiles * a.batch <= SMALL_GEMM_TILES && a.K % SK == 0 && a.K <= 512) {
     dim3 sgrid((unsigned)(4 * tiles), (unsigned)a.batch), block(256);
     if (!AT && BT) hipLaunchKernelGGL((gemm_small_kernel<false, true>), sgrid, block, 0, st, a, 2 * nbn);
     else if (!AT && !BT) hipLaunchKernelGGL((gemm_small_kernel<false, false>), sgrid, block, 0, st, a, 2 * nbn);
@@ -451,19 +450,18 @@ static int build_super_inverses(hipStream_t st, const double *L, int n_pad, doub
   return GPIRT_OK;
 }
 
-// Right-looking blocked Cholesky.  With a second stream the diagonal-block kernel and the
-// panel solve of step k+1 run beside the bulk of step k's trailing update (look-ahead): the
-// first block column of the update is issued on its own so that they can start early.
+// Right-looking blocked Cholesky with two-level blocking: a super-panel of 4 block columns is
+// factored by 128-wide steps (diagonal kernel, panel solve with the inverted diagonal block,
+// update of the rest of the super-panel); the trailing matrix then gets ONE rank-512 update
+// (lower tiles only), which cuts the read-modify-write traffic on it four-fold.  Running the
+// next diagonal step beside a trailing update on a second stream was measured and is not
+// faster: the one-workgroup diagonal kernel needs a whole CU's LDS and only starts when the
+// update, which fills every CU, drains.
 int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, int *d_info,
-                 double *work, hipStream_t st2, hipEvent_t ev_col, hipEvent_t ev_panel) {
+                 double *work) {
   const int nb = n_pad / TILE;
   const int64_t sS = (int64_t)n_pad * n_pad, sI = inv_group_elems(n_pad);
-  // measured: the one-workgroup diagonal kernel needs a whole CU's LDS, so beside a trailing
-  // update that fills every CU it only starts when that update drains; the look-ahead path
-  // is kept for experiments (GPIRT_LOOKAHEAD=1) but is not faster
-  static const bool want_ahead = getenv("GPIRT_LOOKAHEAD") != nullptr;
-  const bool ahead = st2 != nullptr && nb > 2 && want_ahead;
-  auto panel_solve = [&](hipStream_t q, int k) -> int {   // L_ik = A_ik * inv(L_kk)^T, i > k
+  auto panel_solve = [&](int k) -> int {   // L_ik = A_ik * inv(L_kk)^T, i > k
     int rem = nb - 1 - k;
     double *panel = S + (int64_t)(k + 1) * TILE + (int64_t)n_pad * k * TILE;
     GemmArgs p{};
@@ -471,71 +469,34 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
     p.B = inv + inv_block_offset(k); p.ldb = SUP; p.strideB = sI;
     p.C = panel; p.ldc = n_pad; p.strideC = sS;
     p.M = rem * TILE; p.N = TILE; p.K = TILE; p.batch = batch; p.alpha = 1.0; p.beta = 0.0;
-    return launch_gemm(q, false, true, p);
+    return launch_gemm(st, false, true, p);
   };
-  // A_ij -= L_ik L_jk^T for block rows/cols >= k+1+skip; only_first: just block column k+1
-  auto update = [&](hipStream_t q, int k, int skip, bool only_first) -> int {
-    int rem = nb - 1 - k - skip;
-    if (rem <= 0) return GPIRT_OK;
-    double *panel = S + (int64_t)(k + 1 + skip) * TILE + (int64_t)n_pad * k * TILE;
+  auto update_rect = [&](int k, int c0, int c1) -> int {   // cols [c0,c1) by panel k, rows >= c0
+    if (c1 <= c0) return GPIRT_OK;
     GemmArgs u{};
-    u.A = panel; u.lda = n_pad; u.strideA = sS;
-    u.B = panel; u.ldb = n_pad; u.strideB = sS;
-    u.C = S + (int64_t)(k + 1 + skip) * TILE * (n_pad + 1); u.ldc = n_pad; u.strideC = sS;
-    u.M = rem * TILE; u.N = only_first ? TILE : rem * TILE; u.K = TILE; u.batch = batch;
-    u.alpha = -1.0; u.beta = 1.0; u.lower_only = only_first ? 0 : 1;
-    return launch_gemm(q, false, true, u);
+    u.A = S + (int64_t)c0 * TILE + (int64_t)n_pad * k * TILE; u.lda = n_pad; u.strideA = sS;
+    u.B = u.A; u.ldb = n_pad; u.strideB = sS;
+    u.C = S + (int64_t)c0 * TILE * (n_pad + 1); u.ldc = n_pad; u.strideC = sS;
+    u.M = (nb - c0) * TILE; u.N = (c1 - c0) * TILE; u.K = TILE; u.batch = batch;
+    u.alpha = -1.0; u.beta = 1.0;
+    return launch_gemm(st, false, true, u);
   };
-  if (!ahead) {
-    // two-level blocking: a super-panel of 4 block columns is factored by 128-wide steps whose
-    // updates stay inside the panel; the trailing matrix then gets ONE rank-512 update, which
-    // cuts the read-modify-write traffic on it four-fold
-    auto update_rect = [&](int k, int c0, int c1) -> int {   // cols [c0,c1) by panel k, rows >= c0
-      if (c1 <= c0) return GPIRT_OK;
+  for (int o = 0; o < nb; o += 4) {
+    const int oe = min(o + 4, nb);
+    for (int k = o; k < oe; ++k) {
+      GP_TRY(launch_potrf_diag(st, S, n_pad, k, batch, inv, nb, d_info));
+      if (k + 1 < nb) GP_TRY(panel_solve(k));
+      GP_TRY(update_rect(k, k + 1, oe));
+    }
+    if (oe < nb) {
       GemmArgs u{};
-      u.A = S + (int64_t)c0 * TILE + (int64_t)n_pad * k * TILE; u.lda = n_pad; u.strideA = sS;
+      u.A = S + (int64_t)oe * TILE + (int64_t)n_pad * o * TILE; u.lda = n_pad; u.strideA = sS;
       u.B = u.A; u.ldb = n_pad; u.strideB = sS;
-      u.C = S + (int64_t)c0 * TILE * (n_pad + 1); u.ldc = n_pad; u.strideC = sS;
-      u.M = (nb - c0) * TILE; u.N = (c1 - c0) * TILE; u.K = TILE; u.batch = batch;
-      u.alpha = -1.0; u.beta = 1.0;
-      return launch_gemm(st, false, true, u);
-    };
-    for (int o = 0; o < nb; o += 4) {
-      const int oe = min(o + 4, nb);
-      for (int k = o; k < oe; ++k) {
-        GP_TRY(launch_potrf_diag(st, S, n_pad, k, batch, inv, nb, d_info));
-        if (k + 1 < nb) GP_TRY(panel_solve(st, k));
-        GP_TRY(update_rect(k, k + 1, oe));
-      }
-      if (oe < nb) {
-        GemmArgs u{};
-        u.A = S + (int64_t)oe * TILE + (int64_t)n_pad * o * TILE; u.lda = n_pad; u.strideA = sS;
-        u.B = u.A; u.ldb = n_pad; u.strideB = sS;
-        u.C = S + (int64_t)oe * TILE * (n_pad + 1); u.ldc = n_pad; u.strideC = sS;
-        u.M = (nb - oe) * TILE; u.N = u.M; u.K = (oe - o) * TILE; u.batch = batch;
-        u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
-        GP_TRY(launch_gemm(st, false, true, u));
-      }
+      u.C = S + (int64_t)oe * TILE * (n_pad + 1); u.ldc = n_pad; u.strideC = sS;
+      u.M = (nb - oe) * TILE; u.N = u.M; u.K = (oe - o) * TILE; u.batch = batch;
+      u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
+      GP_TRY(launch_gemm(st, false, true, u));
     }
-  } else {
-  GP_TRY(launch_potrf_diag(st, S, n_pad, 0, batch, inv, nb, d_info));
-  if (nb > 1) GP_TRY(panel_solve(st, 0));
-  for (int k = 0; k + 1 < nb; ++k) {
-    if (!ahead) {
-      GP_TRY(update(st, k, 0, false));
-      GP_TRY(launch_potrf_diag(st, S, n_pad, k + 1, batch, inv, nb, d_info));
-      if (k + 2 < nb) GP_TRY(panel_solve(st, k + 1));
-      continue;
-    }
-    GP_TRY(update(st, k, 0, true));                 // block column k+1 of the trailing matrix
-    GP_HIP(hipEventRecord(ev_col, st));
-    GP_HIP(hipStreamWaitEvent(st2, ev_col, 0));
-    GP_TRY(launch_potrf_diag(st2, S, n_pad, k + 1, batch, inv, nb, d_info));
-    if (k + 2 < nb) GP_TRY(panel_solve(st2, k + 1));
-    GP_HIP(hipEventRecord(ev_panel, st2));
-    GP_TRY(update(st, k, 1, false));                // the rest, beside the work on st2
-    GP_HIP(hipStreamWaitEvent(st, ev_panel, 0));
-  }
   }
   if (nb > 1)
     for (int z = 0; z < batch; ++z)

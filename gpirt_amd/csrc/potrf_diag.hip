@@ -91,7 +91,7 @@ __device__ __forceinline__ void blk_range(double (&x)[SB], double (&uc)[SB], dou
 // off-diagonal blocks of the inverse follow by block substitution, again on MFMA.
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S, int n_pad, int kb,
                                                         double *__restrict__ inv_diag, int nb,
-                                                        int *__restrict__ info, int dbg) {
+                                                        int *__restrict__ info) {
   __shared__ __attribute__((aligned(16))) double T[TILE * XLD];
   __shared__ __attribute__((aligned(16))) double dinv[TILE];
   __shared__ __attribute__((aligned(16))) double ucol[2 * SB];
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
   for (int p = 0; p < TILE / SB; ++p) {
     const int i0 = p * SB;
     double *Tp = &T[i0 * XLD + i0];
-    if (wave == 0 && !(dbg & 1)) {
+    if (wave == 0) {
       const int r = lane & 31, half = lane >> 5;
       double x[SB], uc[SB], un[SB];
       // both halves issue the same unconditional loads; the high half then swaps in the identity
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
     const int R = TILE - i0 - SB;                  // rows below the diagonal block
     const int NT = R / 16;
     // panel: L_ip = A_ip * X_pp^T, a wave owns whole 16-row strips (reads before its writes)
-    for (int rb = wave; rb < ((dbg & 2) ? 0 : NT); rb += 4) {
+    for (int rb = wave; rb < NT; rb += 4) {
       const int ib = i0 + SB + 16 * rb;
       v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
     }
     __syncthreads();
     // trailing update on the lower 16x16 tiles: A_ij -= L_ip L_jp^T
-    for (int e = wave; e < ((dbg & 2) ? 0 : NT * (NT + 1) / 2); e += 4) {
+    for (int e = wave; e < NT * (NT + 1) / 2; e += 4) {
       int ti = 0;
       while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
       const int tj = e - ti * (ti + 1) / 2;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
   // X_32 (32x32), level 2 the 64x64 block below the first 64 columns.  All products run on
   // MFMA straight from the image; the inner product M = B A^-1 is parked in the (still
   // unused) destination region of the result, transposed like the result itself.
-  if (!(dbg & 4)) {
+  {
     // ---- level 1: wave = (pair, column strip of 16) --------------------------------------
     {
       const int pair = wave >> 1, cs = wave & 1;
@@ -302,9 +302,8 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
 
 int launch_potrf_diag(hipStream_t st, double *S, int n_pad, int kb, int batch, double *inv_diag, int nb,
                       int *d_info) {
-  static int dbg = getenv("GPIRT_DIAG_DBG") ? atoi(getenv("GPIRT_DIAG_DBG")) : 0;
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, st, S, n_pad, kb, inv_diag, nb,
-                     d_info, dbg);
+                     d_info);
   GP_HIP(hipGetLastError());
   return GPIRT_OK;
 }

@@ -95,8 +95,7 @@ struct gpirt_sampler {
   uint64_t seed;
   uint32_t sweep;
   double jitter_now;
-  hipStream_t st, st2;          // st2 + the two events carry the Cholesky look-ahead
-  hipEvent_t ev_col, ev_panel;
+  hipStream_t st;
   int8_t *d_y, *d_yT;
   double *d_theta, *d_f, *d_Z, *d_nu, *d_S, *d_inv, *d_fwork, *d_xtmp, *d_W, *d_Gt;
   double *d_ebeta, *d_delta, *d_beta, *d_bthr, *d_betaS, *d_bthrS, *d_bpm, *d_bps;
@@ -126,9 +125,6 @@ static void sampler_free(gpirt_sampler *s) {
                   s->d_sum_th, s->d_sum_th2, s->d_sum_p, s->d_sum_arg};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
-  if (s->ev_col) (void)hipEventDestroy(s->ev_col);
-  if (s->ev_panel) (void)hipEventDestroy(s->ev_panel);
-  if (s->st2) (void)hipStreamDestroy(s->st2);
   if (s->st) (void)hipStreamDestroy(s->st);
   delete s;
 }
@@ -244,10 +240,8 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   int rc = GPIRT_OK;
   auto fail = [&](int code) { sampler_free(s); return code; };
   if (hipGetDevice(&s->device) != hipSuccess) return fail(GPIRT_ERR_HIP);
-  if (hipStreamCreate(&s->st) != hipSuccess || hipStreamCreate(&s->st2) != hipSuccess ||
-      hipEventCreateWithFlags(&s->ev_col, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&s->ev_panel, hipEventDisableTiming) != hipSuccess) {
-    set_error("stream/event creation failed");
+  if (hipStreamCreate(&s->st) != hipSuccess) {
+    set_error("stream creation failed");
     return fail(GPIRT_ERR_HIP);
   }
 
@@ -393,8 +387,7 @@ static int phase_factor(gpirt_sampler *s) {
                           s->cfg.irf_sf, s->jitter_now, s->d_S, false));
     GP_TRY(mark(s, PH_POTRF));
     GP_HIP(hipMemsetAsync(s->d_info, 0, sizeof(int), s->st));
-    GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info, s->d_fwork, s->st2,
-                        s->ev_col, s->ev_panel));
+    GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info, s->d_fwork));
     int info = 0;
     GP_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, s->st));
     GP_HIP(hipStreamSynchronize(s->st));
