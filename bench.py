@@ -138,6 +138,25 @@ def main():
             # stream-ordered hook: the collective is enqueued on the sampler's own HIP stream,
             # no host round trip per proposal round (GPIRT_BENCH_SYNC_ALLREDUCE=1: blocking hook)
             on_stream = not os.environ.get("GPIRT_BENCH_SYNC_ALLREDUCE")
+            if on_stream:
+                # try the stream-ordered hook once on a stream of torch's own; every rank falls
+                # back to the blocking hook unless it worked everywhere
+                ok = 1.0
+                try:
+                    probe = torch_allreduce(device_buffers=True, on_stream=True)
+                    side = torch.cuda.Stream()
+                    probe.stream_ptr = side.cuda_stream
+                    ones = torch.ones(1024, dtype=torch.float64, device="cuda")
+                    torch.cuda.synchronize()
+                    probe(ones.data_ptr(), ones.numel())
+                    side.synchronize()
+                    ok = float(bool(torch.all(ones == float(world)).item()))
+                except Exception as exc:                      # noqa: BLE001
+                    print("rank %d: stream-ordered all-reduce unavailable (%s)" % (rank, exc), file=sys.stderr)
+                    ok = 0.0
+                flag = torch.tensor([ok], dtype=torch.float64, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                on_stream = bool(flag.item() > 0.5)
             hook = torch_allreduce(device_buffers=True, on_stream=on_stream)
 
     n, m, C = args.n, args.m, args.C
