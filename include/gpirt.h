@@ -232,7 +232,9 @@ int gpirt_run_summary(const gpirt_config *cfg, const int8_t *y, const double *th
  * whitened beta / threshold parameters and their derived copies, the sweep counter that keys
  * the random streams, the current jitter, the diagnostics counters) as one opaque host
  * blob.  Restoring it into a sampler created with the SAME configuration and data continues
- * the chain bit for bit.  The running sums of the summaries are not part of it. */
+ * the chain bit for bit.  The running sums of the summaries are not part of it.
+ * No counterpart in the reference, whose scripts only save the R workspace after a finished
+ * run (TAPS/gpirt_TAPS.R:41, gpirt_esm.R:86). */
 int64_t gpirt_sampler_checkpoint_bytes(gpirt_sampler *s);
 int gpirt_sampler_checkpoint(gpirt_sampler *s, void *blob, int64_t bytes);
 int gpirt_sampler_restore(gpirt_sampler *s, const void *blob, int64_t bytes);
