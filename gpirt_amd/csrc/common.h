@@ -167,6 +167,10 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
 // xtmp holds 4 * SUP * nrhs_pad doubles per system (split-K slabs of the diagonal steps).
 int launch_potrs(hipStream_t st, const double *L, const double *inv, int n_pad, int batch,
                  double *B, int64_t ldb, int64_t strideB, int nrhs_pad, double *xtmp);
+// the same cross-covariance at an arbitrary list of R nodes (device array), R_pad columns written
+int launch_kstar_nodes(hipStream_t st, const double *x, int64_t x_stride, int n, int n_pad, int batch,
+                       double ls, double sf, const double *nodes, int R, int R_pad, double *Kc,
+                       int64_t group_stride);
 // out[r + ldo*j] = sum_q x[q*slab_stride + r + ldx*j], rows even (split-K partial results)
 int launch_sum_slabs(hipStream_t st, const double *x, int nslab, int64_t slab_stride, int rows,
                      int cols, int64_t ldx, double *out, int64_t ldo);

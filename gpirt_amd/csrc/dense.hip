@@ -413,6 +413,32 @@ int launch_kstar_t(hipStream_t st, const double *x, int64_t x_stride, int n, int
   return GPIRT_OK;
 }
 
+// Kc[r + n_pad*j] = sf^2 exp(-(c_j - x_r)^2 / (2 ls^2)) for the nodes c_0..c_{R-1}, zero outside
+__global__ void kstar_nodes_kernel(const double *__restrict__ x, int64_t x_stride, int n, int n_pad,
+                                   double inv_ls2, double sf2, const double *__restrict__ nodes, int R,
+                                   double *__restrict__ Kc, int64_t group_stride) {
+  const int z = blockIdx.z;
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = blockIdx.y;
+  if (r >= n_pad) return;
+  double v = 0.0;
+  if (r < n && j < R) {
+    double d = nodes[j] - x[x_stride * z + r];
+    v = sf2 * exp(-0.5 * d * d * inv_ls2);
+  }
+  Kc[group_stride * z + r + (int64_t)n_pad * j] = v;
+}
+
+int launch_kstar_nodes(hipStream_t st, const double *x, int64_t x_stride, int n, int n_pad, int batch,
+                       double ls, double sf, const double *nodes, int R, int R_pad, double *Kc,
+                       int64_t group_stride) {
+  dim3 block(256), grid((n_pad + 255) / 256, R_pad, batch);
+  hipLaunchKernelGGL(kstar_nodes_kernel, grid, block, 0, st, x, x_stride, n, n_pad, 1.0 / (ls * ls),
+                     sf * sf, nodes, R, Kc, group_stride);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
 // defined in potrf_diag.hip
 int launch_potrf_diag(hipStream_t st, double *S, int n_pad, int kb, int batch, double *inv_diag, int nb,
                       int *d_info);

@@ -103,6 +103,8 @@ struct gpirt_sampler {
   double *d_llu;
   double *d_onehot, *d_T, *d_lp;   // static (grid) respondent step only
   double *d_sum_th, *d_sum_th2, *d_sum_p, *d_sum_arg;   // running sums of the summaries (lazy)
+  double *d_nodes, *d_lag;   // Chebyshev nodes on the grid's range and the interpolation matrix
+  int fs_nodes, fs_rank;     // nodes in use and their padded count (0: exact cross-covariance)
   int summary_draws;
   int32_t *d_done, *d_info, *d_remaining;
   unsigned long long *d_counters;  // [3][2]: f, param, theta x (evaluations, capped)
@@ -122,7 +124,7 @@ static void sampler_free(gpirt_sampler *s) {
                   s->d_bpm, s->d_bps, s->d_xc, s->d_tnu, s->d_prop, s->d_hh, s->d_phi, s->d_pmin,
                   s->d_pmax, s->d_buf, s->d_Lt, s->d_tpm, s->d_tps, s->d_llu, s->d_done, s->d_info,
                   s->d_remaining, s->d_counters, s->d_onehot, s->d_T, s->d_lp,
-                  s->d_sum_th, s->d_sum_th2, s->d_sum_p, s->d_sum_arg};
+                  s->d_sum_th, s->d_sum_th2, s->d_sum_p, s->d_sum_arg, s->d_nodes, s->d_lag};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
   if (s->st) (void)hipStreamDestroy(s->st);
@@ -143,6 +145,60 @@ static void params_host(const gpirt_sampler *s, int jl, const double *e, const d
   b[0] = -INFINITY; b[C] = INFINITY;
   b[1] = dl[0];
   for (int c = 2; c < C; ++c) b[c] = b[c - 1] + exp(dl[c - 1]);
+}
+
+// The f* step needs K(x, xs) S^-1 F on the G = 1001 grid points.  As a function of the grid
+// point, sf^2 exp(-(x - s)^2 / (2 ls^2)) is entire, so it is reproduced to rounding error by
+// polynomial interpolation from R Chebyshev nodes on the grid's range:
+//     K(x, xs) = K(x, c) Lag,   Lag[j, g] = l_j(xs_g)   (barycentric Lagrange basis),
+// and the solve needs R (128) right-hand sides instead of G (1024).  R is accepted only if the
+// interpolation error, measured here on a spread of x, is below 1e-13 sf^2; otherwise (short
+// length scales) the step falls back to the exact cross-covariance.
+static int setup_fstar_interpolation(gpirt_sampler *s) {
+  const int G = s->G, G_pad = s->G_pad;
+  const double lo = s->cfg.grid_lo, hi = lo + s->cfg.grid_step * (G - 1), ls = s->cfg.irf_ls;
+  const double kPi = 3.14159265358979323846;
+  for (int R = TILE; R <= 2 * TILE && R < G; R += TILE) {
+    std::vector<double> c(R), w(R);
+    for (int j = 0; j < R; ++j) {
+      c[j] = 0.5 * (lo + hi) + 0.5 * (hi - lo) * cos(kPi * j / (R - 1));
+      w[j] = (j & 1) ? -1.0 : 1.0;
+    }
+    w[0] *= 0.5; w[R - 1] *= 0.5;
+    std::vector<double> lag((size_t)R * G_pad, 0.0);          // [R, G_pad], node index contiguous
+    for (int g = 0; g < G; ++g) {
+      const double xg = lo + s->cfg.grid_step * g;
+      int hit = -1;
+      double den = 0.0;
+      for (int j = 0; j < R; ++j) {
+        if (xg == c[j]) { hit = j; break; }
+        den += w[j] / (xg - c[j]);
+      }
+      for (int j = 0; j < R; ++j)
+        lag[j + (size_t)R * g] = hit >= 0 ? (j == hit ? 1.0 : 0.0) : (w[j] / (xg - c[j])) / den;
+    }
+    double err = 0.0;
+    for (int t = 0; t <= 240 && err <= 1e-13; ++t) {
+      const double x = (lo - 3.0) + (hi - lo + 6.0) * t / 240.0;
+      std::vector<double> kc(R);
+      for (int j = 0; j < R; ++j) kc[j] = exp(-0.5 * (c[j] - x) * (c[j] - x) / (ls * ls));
+      for (int g = 0; g < G; g += 7) {
+        double acc = 0.0;
+        for (int j = 0; j < R; ++j) acc += kc[j] * lag[j + (size_t)R * g];
+        const double xg = lo + s->cfg.grid_step * g;
+        err = fmax(err, fabs(acc - exp(-0.5 * (xg - x) * (xg - x) / (ls * ls))));
+      }
+    }
+    if (err > 1e-13) continue;
+    GP_TRY(dalloc(s->d_nodes, (size_t)R));
+    GP_TRY(dalloc(s->d_lag, (size_t)R * G_pad));
+    GP_HIP(hipMemcpy(s->d_nodes, c.data(), sizeof(double) * R, hipMemcpyHostToDevice));
+    GP_HIP(hipMemcpy(s->d_lag, lag.data(), sizeof(double) * lag.size(), hipMemcpyHostToDevice));
+    s->fs_nodes = R; s->fs_rank = R;
+    return GPIRT_OK;
+  }
+  s->fs_rank = 0;
+  return GPIRT_OK;
 }
 
 static int check_cfg(const gpirt_config *cfg) {
@@ -342,6 +398,9 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   UP_(s->d_betaS, hbetaS); UP_(s->d_bthrS, hbS); UP_(s->d_Lt, hLt); UP_(s->d_tpm, htpm);
   UP_(s->d_tps, htps);
 #undef UP_
+  if (!(cfg->flags & GPIRT_EXACT_FSTAR)) {
+    if ((rc = setup_fstar_interpolation(s))) return fail(rc);
+  }
   if (cfg->theta_mode == GPIRT_THETA_GRID) {
     if ((rc = launch_grid_onehot(s->st, s->d_yT, n, mloc, ML, C, s->d_onehot))) return fail(rc);
     if (hipStreamSynchronize(s->st) != hipSuccess) { set_error("one-hot coding failed"); return fail(GPIRT_ERR_HIP); }
@@ -444,6 +503,46 @@ static int phase_fstar(gpirt_sampler *s) {
   // side has fewer columns: W = S^-1 K(x,xs) (G columns, the same on every rank) or
   // alpha = S^-1 F (this rank's units: fewer than G once the items are sharded, and then no
   // rank repeats another's solve).
+  if (s->fs_rank > 0) {
+    // interpolated cross-covariance: solve for the R node columns only,
+    //   Y = F^T S^-1 K(x, c)   [units x R],   f*^T = Y Lag   [units x G]
+    const int R = s->fs_rank;
+    GP_TRY(launch_kstar_nodes(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
+                              s->cfg.irf_sf, s->d_nodes, s->fs_nodes, R, s->d_W,
+                              (int64_t)s->Np_pad * s->G_pad));
+    GP_TRY(launch_potrs(s->st, s->d_S, s->d_inv, s->Np_pad, s->P, s->d_W, s->Np_pad,
+                        (int64_t)s->Np_pad * s->G_pad, R, s->d_xtmp));
+    double *Y = s->d_nu;          // [U_pad, R], free between the f step and the next sweep
+    GemmArgs g{};
+    g.A = s->d_f; g.lda = s->Np_pad; g.strideA = (int64_t)s->Np_pad * s->ML;
+    g.B = s->d_W; g.ldb = s->Np_pad; g.strideB = (int64_t)s->Np_pad * s->G_pad;
+    g.C = Y; g.ldc = s->U_pad; g.strideC = s->ML;
+    g.M = s->ML; g.N = R; g.K = s->Np_pad; g.batch = s->P; g.alpha = 1.0; g.beta = 0.0;
+    const int64_t tiles = (int64_t)(s->ML / TILE) * (R / TILE);
+    int splits = 1;
+    if (s->P == 1 && tiles < 512 && s->Np_pad >= 2048) {
+      const int slabs = s->Np_pad / 16;
+      const int64_t room = ((int64_t)s->Np_pad * s->U_pad) / ((int64_t)s->ML * R);
+      for (int q = 2; q <= 16 && q <= room && tiles * q <= 1024; ++q)
+        if (slabs % q == 0) splits = q;
+    }
+    if (splits > 1) {   // few output tiles, long K: partial products parked in Z, then summed
+      const int kc = s->Np_pad / splits;
+      g.K = kc; g.batch = splits; g.strideA = kc; g.strideB = kc;
+      g.C = s->d_Z; g.ldc = s->ML; g.strideC = (int64_t)s->ML * R;
+      GP_TRY(launch_gemm(s->st, true, false, g));
+      GP_TRY(launch_sum_slabs(s->st, s->d_Z, splits, g.strideC, s->ML, R, s->ML, Y, s->U_pad));
+    } else {
+      GP_TRY(launch_gemm(s->st, true, false, g));
+    }
+    GemmArgs h{};
+    h.A = Y; h.lda = s->U_pad; h.strideA = s->ML;
+    h.B = s->d_lag; h.ldb = R; h.strideB = 0;
+    h.C = s->d_Gt; h.ldc = s->U_pad; h.strideC = s->ML;
+    h.M = s->ML; h.N = s->G_pad; h.K = R; h.batch = s->P; h.alpha = 1.0; h.beta = 0.0;
+    GP_TRY(launch_gemm(s->st, false, false, h));
+    return GPIRT_OK;
+  }
   GP_TRY(launch_kstar_t(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
                         s->cfg.irf_sf, s->G, s->G_pad, s->cfg.grid_lo, s->cfg.grid_step, s->d_W));
   const double *lhs = s->d_f;

@@ -61,6 +61,8 @@ typedef enum gpirt_theta_mode {
 enum {
   GPIRT_RETURN_F = 1,      /* copy each kept draw of f back (large: n*m*H doubles per draw) */
   GPIRT_RETURN_FSTAR = 2,  /* copy each kept draw of f* back (n_grid*m*P doubles per draw)  */
+  GPIRT_EXACT_FSTAR = 8,   /* evaluate K(x, xs) at every grid point in the f* step instead of
+                              interpolating it from Chebyshev nodes (see gpirt_sampler_sweep)  */
   GPIRT_ALLREDUCE_ON_STREAM = 4 /* the all-reduce hook ENQUEUES the collective on the sampler's
                               HIP stream (gpirt_sampler_stream) and returns without waiting;
                               the library then does not drain the stream around the call and

@@ -162,8 +162,11 @@ def _pair(cfg, y, **kw):
     return Sampler(cfg, y, **kw), oracle.Sampler(cfg, y, **kw)
 
 
-@pytest.mark.parametrize("stem,C,const", [("2PL_C_2", 2, 0), ("Wiener_C_5", 5, 0), ("2PL_C_5", 5, 1)])
-def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const):
+@pytest.mark.parametrize("stem,C,const,flags", [("2PL_C_2", 2, 0, 0), ("Wiener_C_5", 5, 0, 0),
+                                                 ("2PL_C_5", 5, 1, 0),
+                                                 ("Wiener_C_5", 5, 0, _abi.EXACT_FSTAR),
+                                                 ("2PL_C_5", 5, 1, _abi.EXACT_FSTAR)])
+def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const, flags):
     """Three whole sweeps from the same state with the shared generator: every accept /
     shrink decision must coincide, so the states agree to rounding.  Tolerance 1e-5: f* goes
     through solves with K + 1e-6 I (condition ~1e9), which bounds agreement of anything
@@ -173,7 +176,7 @@ def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const):
     theta = d["theta"][:, :y.shape[2]]
     n, m, H = y.shape
     cfg = _abi.default_config(n=n, m=m, H=H, C=C, seed=5, theta_os=1.0, theta_ls=H / 2,
-                              constant_irf=const)
+                              constant_irf=const, flags=flags)
     g, c = _pair(cfg, y, theta_init=theta)
     for sweep in range(3):
         g.sweep(1); c.sweep(1)
@@ -188,14 +191,15 @@ def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const):
     g.close(); c.close()
 
 
-@pytest.mark.parametrize("n,m,sweeps", [(1300, 9, 2), (2100, 5, 1)])
-def test_sweep_matches_oracle_wide_units(n, m, sweeps):
+@pytest.mark.parametrize("n,m,sweeps,flags", [(1300, 9, 2, 0), (2100, 5, 1, 0),
+                                              (2100, 5, 1, _abi.EXACT_FSTAR)])
+def test_sweep_matches_oracle_wide_units(n, m, sweeps, flags):
     """n >= 1024 rows per unit switches the item kernels to one workgroup per unit and the
     Cholesky to several diagonal blocks (ragged last super-block); n >= 2048 also splits the
     K range of the f* product into partial sums: same parity bar."""
     from gpirt_amd.synth import generate
     d = generate(n, m, 3, seed=4)
-    cfg = _abi.default_config(n=n, m=m, H=1, C=3, seed=8)
+    cfg = _abi.default_config(n=n, m=m, H=1, C=3, seed=8, flags=flags)
     g, c = _pair(cfg, d["y"], theta_init=d["theta"])
     for sweep in range(sweeps):
         g.sweep(1); c.sweep(1)
@@ -208,12 +212,14 @@ def test_sweep_matches_oracle_wide_units(n, m, sweeps):
     g.close(); c.close()
 
 
-def test_sweep_matches_oracle_many_items():
-    """More unit columns than grid points (ML >= G_pad = 1024): the f* phase then solves
-    S^-1 K(x, xs) instead of S^-1 F.  Same parity bar."""
+@pytest.mark.parametrize("flags", [0, _abi.EXACT_FSTAR])
+def test_sweep_matches_oracle_many_items(flags):
+    """More unit columns than grid points (ML >= G_pad = 1024): with the exact cross-covariance
+    the f* phase then solves S^-1 K(x, xs) instead of S^-1 F; by default it solves for the
+    Chebyshev-node columns only.  Same parity bar."""
     from gpirt_amd.synth import generate
     d = generate(70, 1030, 3, seed=6)
-    cfg = _abi.default_config(n=70, m=1030, H=1, C=3, seed=2)
+    cfg = _abi.default_config(n=70, m=1030, H=1, C=3, seed=2, flags=flags)
     g, c = _pair(cfg, d["y"], theta_init=d["theta"])
     for sweep in range(2):
         g.sweep(1); c.sweep(1)
