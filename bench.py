@@ -31,6 +31,36 @@ def dense_flops(n, m, G):
     return dict(potrf=n ** 3 / 3.0, nu=float(n) * n * m, fstar=2.0 * n * n * m + 2.0 * G * n * m)
 
 
+def substeps(n, m, C, G, ms, evals):
+    """Achieved rate of every sub-step of the sweep from its ALGORITHMIC work (the counts of the
+    reference's formulation: Cholesky n^3/3, L*Z n^2 m, f* by two triangular solves per item
+    2 n^2 m + 2 G n m, a likelihood pass n m cells of 8 B f + 1 B y, an f proposal 17 B/cell)
+    and its measured time.  The f* step executes far fewer flop than that count (the solve runs
+    on 128 interpolation-node columns), so its rate can exceed the matrix peak; `executed_flop`
+    says what was actually run."""
+    def rate(flop, t):
+        return flop / (t * 1e-3) / 1e12 if t > 0 else 0.0
+    cells_f, cells_p, cells_t = evals["ess_f_rounds"] * n, evals["ess_param_rounds"] * n, evals["ess_theta_rounds"] * n * m
+    fstar_exec = 2.0 * n * n * 128 + 2.0 * n * m * 128 + 2.0 * 128 * G * m
+    out = {
+        "potrf": {"ms": ms["potrf"], "algorithmic_flop": n ** 3 / 3.0, "tflops": rate(n ** 3 / 3.0, ms["potrf"])},
+        "nu=L*Z": {"ms": ms["nu"], "algorithmic_flop": float(n) * n * m, "tflops": rate(float(n) * n * m, ms["nu"])},
+        "fstar": {"ms": ms["fstar"], "algorithmic_flop": 2.0 * n * n * m + 2.0 * G * n * m,
+                  "executed_flop": fstar_exec, "tflops_algorithmic": rate(2.0 * n * n * m + 2.0 * G * n * m, ms["fstar"]),
+                  "tflops_executed": rate(fstar_exec, ms["fstar"])},
+        "k_build": {"ms": ms["k_build"], "algorithmic_bytes": 8.0 * n * n,
+                    "GBps": 8.0 * n * n / (ms["k_build"] * 1e-3) / 1e9 if ms["k_build"] > 0 else 0.0},
+    }
+    for name, cells, bpc in (("ess_f", cells_f, 17.0), ("ess_param", cells_p, 9.0), ("theta", cells_t, 9.0)):
+        t = ms[name]
+        out[name] = {"ms": t, "cells": cells, "Gcells_per_s": cells / (t * 1e-3) / 1e9 if t > 0 else 0.0,
+                     "algorithmic_GBps": cells * bpc / (t * 1e-3) / 1e9 if t > 0 else 0.0}
+    # the respondent step counts every respondent in every lock-step round, although those
+    # that have accepted drop out: its cell count is an upper bound
+    out["theta"]["cells_are_upper_bound"] = True
+    return out
+
+
 def pmc_traffic(n, m, world):
     """HBM bytes per launch of the nu = L*Z kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE doubled as the gfx950 correction asks, plus WRITE_SIZE); counters cannot be
@@ -236,6 +266,7 @@ def main():
                 "flop_per_launch": fl["nu"], "ms_per_launch": nu_ms,
                 "traffic": pmc_traffic(n, m, world),
             },
+            "substeps": substeps(n, mloc, C, cfg.n_grid, phases, evals),
             "phases_ms": phases,
             "launch_marks_per_step": launches,
             "dense_tflops": (fl["potrf"] + fl["nu"] + fl["fstar"]) / (dense_ms * 1e-3) / 1e12 if dense_ms > 0 else 0.0,
