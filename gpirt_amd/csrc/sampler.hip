@@ -622,7 +622,10 @@ static int phase_theta(gpirt_sampler *s) {
   const bool sharded = s->cfg.world > 1 && !(s->cfg.flags & GPIRT_ALLREDUCE_ON_STREAM);
   GP_HIP(hipMemsetAsync(s->d_remaining, 0, sizeof(int) * (size_t)(R + 2), s->st));
   GP_TRY(launch_theta_prepare(s->st, a));
-  GP_TRY(launch_theta_eval(s->st, a, 1, false));
+  // a workgroup per respondent pays off once a respondent has enough items to keep four waves
+  // busy, and always when few respondents are still active (latency of one respondent's loop)
+  const bool many_items = s->mloc * s->H >= 1024;
+  GP_TRY(launch_theta_eval(s->st, a, 1, many_items));
   GP_TRY(exchange(s));
   s->theta_rounds++;
   GP_TRY(launch_theta_decide(s->st, a, 0));
@@ -632,7 +635,7 @@ static int phase_theta(gpirt_sampler *s) {
   while (r <= R) {
     // rounds r .. last run without a look at the counters
     const int last = sharded ? r : min(R, r < 6 ? 6 : r + 2);
-    const bool wide = active * 4 <= s->n;
+    const bool wide = many_items || active * 4 <= s->n;
     for (int q = r; q <= last; ++q) {
       GP_TRY(launch_theta_eval(s->st, a, 0, wide));
       GP_TRY(exchange(s));
