@@ -1,0 +1,129 @@
+"""The benchmark's sizes (n = 10 000 respondents, m = 4096 items, C = 5), where the CPU oracle
+would need minutes per sweep: the device path is checked through properties that do not
+depend on the size -- backward error of the factorisation against matrix-vector products,
+linearity of the triangular product, residual of the solve, a checksum of checksums for the
+two log-likelihood reductions, additivity over a split of the rows, and the invariants one
+sweep must leave behind (utils/elliptical_slice.m:47-102, main.m:57-73)."""
+import numpy as np
+import pytest
+
+from gpirt_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+N, M, C = 10000, 4096, 5
+
+
+@pytest.fixture(scope="module")
+def K():
+    from gpirt_amd import kernels
+    return kernels
+
+
+@pytest.fixture(scope="module")
+def factor(K):
+    """theta ~ N(0,1), S = K(theta, theta) + 1e-6 I, L = chol(S): main.m:29,67, sample_fs.m:2."""
+    x = np.random.default_rng(1).normal(size=N)
+    S = K.k_build(x, 1.0, 1.0, 1e-6)
+    return x, S, K.potrf(S)
+
+
+def test_kernel_matrix_entries(factor):
+    x, S, _ = factor
+    rows = np.random.default_rng(2).integers(0, N, size=64)
+    want = np.exp(-0.5 * (x[rows, None] - x[None, :]) ** 2)
+    want[np.arange(64), rows] += 1e-6
+    assert np.abs(S[rows] - want).max() < 1e-15          # one exp per entry
+    assert np.array_equal(S[rows], S[:, rows].T)         # symmetric bit for bit
+
+
+def test_cholesky_backward_error(factor):
+    """|S v - L (L^T v)| <= c n eps |S| |v| for random v: the factor reproduces the matrix
+    to the backward error of a Cholesky factorisation although its condition is ~1e10."""
+    _, S, L = factor
+    assert np.all(np.diag(L) > 0)
+    for j in range(0, N, 1250):                          # strictly upper part: exact zeros
+        assert not L[j:j + 1250, j + 1250:].any()
+        assert not np.triu(L[j:j + 1250, j:j + 1250], 1).any()
+    V = np.random.default_rng(3).normal(size=(N, 6))
+    R = S @ V - L @ (L.T @ V)
+    scale = np.linalg.norm(S, 2 if N <= 2000 else "fro") * np.linalg.norm(V)
+    assert np.linalg.norm(R) < 1e-14 * scale
+
+
+def test_triangular_product_linearity_and_value(K, factor):
+    """nu = L Z (elliptical_slice.m:64) for 96 columns: against numpy, and linear in Z."""
+    _, _, L = factor
+    rng = np.random.default_rng(4)
+    Z1, Z2 = rng.normal(size=(N, 96)), rng.normal(size=(N, 96))
+    A1, A2, A3 = K.trmm_lz(L, Z1), K.trmm_lz(L, Z2), K.trmm_lz(L, 0.5 * Z1 - 3.0 * Z2)
+    want = L @ Z1
+    tol = 1e-12 * np.sqrt(N) * max(1.0, np.abs(want).max())
+    assert np.abs(A1 - want).max() < tol
+    assert np.abs(A3 - (0.5 * A1 - 3.0 * A2)).max() < tol
+
+
+def test_solve_residual(K, factor):
+    """X = S^-1 B through the factor (the two solves of main.m:57-58): residual at the level
+    of the backward error, i.e. relative to |S| |X|, not to |B| (the condition is ~1e10)."""
+    _, S, L = factor
+    B = S @ np.random.default_rng(5).normal(size=(N, 8))     # a right-hand side with a tame solution
+    X = K.potrs(L, B)
+    R = S @ X - B
+    assert np.linalg.norm(R) < 1e-13 * np.linalg.norm(S, "fro") * np.linalg.norm(X)
+
+
+def test_loglik_checksum_of_checksums_and_additivity(K):
+    """Per-item and per-respondent sums of the same cells (log_like_fn.m:3-4 in the ordinal
+    form of gpirt-sythetic.R:159-167) must have the same total, and masking the two halves of
+    the rows in turn must split every per-item sum in two."""
+    rng = np.random.default_rng(6)
+    g = 1.5 * rng.normal(size=(N, M))
+    y = rng.integers(0, C + 1, size=(N, M)).astype(np.int8)        # 0 = missing
+    b = np.zeros((C + 1, M))
+    b[1:C] = np.sort(rng.normal(size=(C - 1, M)), axis=0)
+    b[0], b[C] = -np.inf, np.inf
+    lu, lr = K.ordinal_loglik(g, y, b)
+    assert np.isfinite(lu).all() and np.isfinite(lr).all()
+    assert abs(lu.sum() - lr.sum()) < 1e-12 * abs(lu.sum())
+    top, bottom = y.copy(), y.copy()
+    top[N // 2:] = 0
+    bottom[:N // 2] = 0
+    lu_t, lr_t = K.ordinal_loglik(g, top, b)
+    lu_b, lr_b = K.ordinal_loglik(g, bottom, b)
+    assert np.allclose(lu_t + lu_b, lu, rtol=1e-12, atol=0)
+    assert np.array_equal(lr_t[:N // 2], lr[:N // 2]) and not lr_t[N // 2:].any()
+    assert np.array_equal(lr_b[N // 2:], lr[N // 2:]) and not lr_b[:N // 2].any()
+
+
+@pytest.mark.parametrize("flags", [0, _abi.EXACT_FSTAR])
+def test_sweep_invariants(flags):
+    """Two sweeps of the benchmark configuration.  Whatever was drawn: thresholds stay ordered
+    with infinite ends, no slice update ran into the round cap, f was re-anchored on the grid
+    curve at each respondent's new theta (main.m:69-73), and the interpolated and the exact
+    cross-covariance of the f* step (main.m:57-58) lead to the same chain."""
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synth import generate
+    d = generate(N, M, C, seed=1)
+    cfg = _abi.default_config(n=N, m=M, H=1, C=C, seed=3, flags=flags)
+    with Sampler(cfg, d["y"], theta_init=d["theta"]) as s:
+        s.sweep(2)
+        st, dg = s.state(), s.diagnostics()
+    th, f, fs, thr = st["theta"][:, 0], st["f"][:, :, 0], st["fstar"][:, :, 0], st["threshold"][:, :, 0]
+    assert dg["ess_capped"] == 0 and dg["jitter_retries"] == 0
+    assert np.isfinite(th).all()
+    assert np.isneginf(thr[:, 0]).all() and np.isposinf(thr[:, C]).all()
+    assert (np.diff(thr[:, 1:C], axis=1) > 0).all()
+    idx = np.clip(np.rint((th + 5.0) / 0.01).astype(np.int64), 0, 1000)   # int64() rounds, main.m:70
+    near = np.abs(f - fs[idx]).max(axis=1)
+    # the re-anchoring is a gather: exact wherever the index computed here is the device's
+    # (a theta within rounding of a grid point may fall on either side)
+    assert (near == 0).mean() > 0.999
+    assert np.corrcoef(th, d["theta"][:, 0])[0, 1] > 0.9        # one early draw, started at the truth
+    key = ("theta", "f", "fstar", "beta")
+    if flags == 0:
+        test_sweep_invariants.first = {k: st[k] for k in key}
+    elif getattr(test_sweep_invariants, "first", None) is not None:
+        for k in key:
+            # same decisions, values equal to the accuracy of the solves with K + 1e-6 I
+            assert np.abs(st[k] - test_sweep_invariants.first[k]).max() < 1e-5, k
