@@ -63,6 +63,14 @@ struct ThetaArgs {
   const double *Gt;         // [U_pad, G_pad] f* with the unit index contiguous
   const double *betaS, *bthrS;
   const int8_t *yT;         // [ML*H, n] responses, respondent-major
+  double *tab;              // [U_pad, C, G] log cell probabilities on the grid (table variant) or null
+  // bucketed evaluation of the table variant (H = 1): respondents grouped by grid index
+  int32_t *gidx, *order;    // [n] grid index of the evaluated theta (-1: not active), respondents by bucket
+  int32_t *bstart;          // [G+1] bucket g holds order[bstart[g] .. bstart[g+1])
+  int32_t *ghist;           // [G] respondents per grid index, counted by the prepare / decision kernels
+  double *part;             // [nchunks, n] partial sums per item chunk
+  int chunk, nchunks;       // items per chunk (multiple of 64), number of chunks
+  int from_parts;           // the decision kernel sums `part` itself instead of reading `buf`
   int n, H, C, mloc, ML, U_pad, G, constant_irf, R;
   double grid_lo, grid_step;
   double os2;               // prior variance of the static step (theta_os^2, 1 when theta_os = 0)
@@ -72,6 +80,15 @@ struct ThetaArgs {
 };
 int launch_theta_prepare(hipStream_t st, const ThetaArgs &a);
 int launch_theta_eval(hipStream_t st, const ThetaArgs &a, int initial, bool wide);
+// tab[u + U_pad*(c + C*g)] = log P(y = c+1 | F*_u(x_g)); with a.tab set, launch_theta_eval sums
+// table entries instead of evaluating cells
+int launch_theta_table(hipStream_t st, const ThetaArgs &a);
+// H = 1, table variant: group the active respondents by the grid index of the theta to be
+// evaluated; every (grid index, item chunk) stages its table rows in LDS once and serves all
+// respondents of the bucket; buf[i] = sum of the chunk partials in fixed order
+constexpr int THETA_BUCKET_MAX_G = 2048;
+int theta_bucket_chunk(int C);
+int launch_theta_eval_bucketed(hipStream_t st, const ThetaArgs &a, int initial);
 int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int round);
 // static (grid) respondent step, H = 1: one-hot coding of y (k = jl + ML*(y-1), ld = C*ML),
 // the per-sweep table of log cell probabilities T[G_pad, C*ML], and the inverse-CDF draw

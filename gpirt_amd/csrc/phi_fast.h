@@ -68,14 +68,18 @@ __device__ inline double phi_upper(double z, const double *s) {   // Phi(-z), z 
   return exp_neg(h, l, s) * g;
 }
 
-// P(zlo < Z <= zhi), floored so that a vanished cell stays finite
-__device__ inline double ordinal_cell_prob(double zlo, double zhi, const double *s) {
-  zlo = fmax(zlo, -1e30);                      // +-inf thresholds: keep the arithmetic finite
-  zhi = fmin(zhi, 1e30);
-  const double e1 = phi_upper(fabs(zlo), s), e2 = phi_upper(fabs(zhi), s);
+// P(zlo < Z <= zhi) from the two tails e1 = Phi(-|zlo|), e2 = Phi(-|zhi|) (zlo, zhi already
+// clamped to finite values), floored so that a vanished cell stays finite
+__device__ inline double ordinal_cell_from_tails(double zlo, double zhi, double e1, double e2) {
   double p = zlo >= 0.0 ? e1 - e2 : (zhi <= 0.0 ? e2 - e1 : (1.0 - e1) - e2);
   if (!(p > kPFloor)) p = kPFloor;
   return p;
+}
+
+__device__ inline double ordinal_cell_prob(double zlo, double zhi, const double *s) {
+  zlo = fmax(zlo, -1e30);                      // +-inf thresholds: keep the arithmetic finite
+  zhi = fmin(zhi, 1e30);
+  return ordinal_cell_from_tails(zlo, zhi, phi_upper(fabs(zlo), s), phi_upper(fabs(zhi), s));
 }
 
 __device__ inline double ordinal_cell_fast(double zlo, double zhi, const double *s) {

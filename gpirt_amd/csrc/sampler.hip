@@ -102,6 +102,10 @@ struct gpirt_sampler {
   double *d_xc, *d_tnu, *d_prop, *d_hh, *d_phi, *d_pmin, *d_pmax, *d_buf, *d_Lt, *d_tpm, *d_tps;
   double *d_llu;
   double *d_onehot, *d_T, *d_lp;   // static (grid) respondent step only
+  double *d_tab;                   // slice respondent step, table variant: [U_pad, C, G] (else null)
+  double *d_part;                  // bucketed evaluation of the table variant (H = 1, else null)
+  int32_t *d_gidx, *d_order, *d_bstart, *d_ghist;
+  int th_chunk, th_nchunks;
   double *d_sum_th, *d_sum_th2, *d_sum_p, *d_sum_arg;   // running sums of the summaries (lazy)
   double *d_nodes, *d_lag;   // Chebyshev nodes on the grid's range and the interpolation matrix
   int fs_nodes, fs_rank;     // nodes in use and their padded count (0: exact cross-covariance)
@@ -124,7 +128,8 @@ static void sampler_free(gpirt_sampler *s) {
                   s->d_bpm, s->d_bps, s->d_xc, s->d_tnu, s->d_prop, s->d_hh, s->d_phi, s->d_pmin,
                   s->d_pmax, s->d_buf, s->d_Lt, s->d_tpm, s->d_tps, s->d_llu, s->d_done, s->d_info,
                   s->d_remaining, s->d_counters, s->d_onehot, s->d_T, s->d_lp,
-                  s->d_sum_th, s->d_sum_th2, s->d_sum_p, s->d_sum_arg, s->d_nodes, s->d_lag};
+                  s->d_sum_th, s->d_sum_th2, s->d_sum_p, s->d_sum_arg, s->d_nodes, s->d_lag, s->d_tab,
+                  s->d_part, s->d_gidx, s->d_order, s->d_bstart, s->d_ghist};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
   if (s->st) (void)hipStreamDestroy(s->st);
@@ -335,6 +340,18 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     A_(s->d_onehot, (size_t)C * ML * Np_pad);
     A_(s->d_T, (size_t)G_pad * C * ML);
     A_(s->d_lp, (size_t)G_pad * Np_pad);
+  } else {
+    // a respondent's likelihood is a function of the grid index: from about a thousand
+    // respondents on, tabulating it once per sweep is cheaper than evaluating cells per round
+    const bool table = (cfg->flags & GPIRT_THETA_TABLE) ||
+                       (n >= 1024 && !(cfg->flags & GPIRT_THETA_DIRECT));
+    if (table) A_(s->d_tab, (size_t)U_pad * C * s->G);
+    if (table && H == 1 && s->G <= THETA_BUCKET_MAX_G) {
+      s->th_chunk = theta_bucket_chunk(C);
+      s->th_nchunks = (mloc + s->th_chunk - 1) / s->th_chunk;
+      A_(s->d_part, (size_t)s->th_nchunks * n);
+      A_(s->d_gidx, n); A_(s->d_order, n); A_(s->d_bstart, (size_t)s->G + 1); A_(s->d_ghist, s->G);
+    }
   }
 #undef A_
 
@@ -594,6 +611,10 @@ static ThetaArgs theta_args(gpirt_sampler *s) {
   a.R = s->cfg.max_ess_rounds; a.grid_lo = s->cfg.grid_lo; a.grid_step = s->cfg.grid_step;
   a.seed = s->seed; a.sweep = s->sweep; a.remaining = s->d_remaining;
   a.counters = s->d_counters + 4;
+  a.tab = s->d_tab;
+  a.part = s->d_part; a.gidx = s->d_gidx; a.order = s->d_order; a.bstart = s->d_bstart;
+  a.ghist = s->d_ghist;
+  a.chunk = s->th_chunk; a.nchunks = s->th_nchunks;
   a.os2 = s->cfg.theta_os > 0 ? s->cfg.theta_os * s->cfg.theta_os : 1.0;
   return a;
 }
@@ -621,23 +642,33 @@ static int phase_theta(gpirt_sampler *s) {
   // a hook that is not stream-ordered passes through the host every round anyway
   const bool sharded = s->cfg.world > 1 && !(s->cfg.flags & GPIRT_ALLREDUCE_ON_STREAM);
   GP_HIP(hipMemsetAsync(s->d_remaining, 0, sizeof(int) * (size_t)(R + 2), s->st));
+  if (a.part) GP_HIP(hipMemsetAsync(s->d_ghist, 0, sizeof(int32_t) * (size_t)s->G, s->st));
   GP_TRY(launch_theta_prepare(s->st, a));
+  if (a.tab) GP_TRY(launch_theta_table(s->st, a));
   // a workgroup per respondent pays off once a respondent has enough items to keep four waves
   // busy, and always when few respondents are still active (latency of one respondent's loop)
   const bool many_items = s->mloc * s->H >= 1024;
-  GP_TRY(launch_theta_eval(s->st, a, 1, many_items));
+  // table variant, H = 1: while a good share of the respondents is active, evaluate them
+  // grouped by grid index (each table row is then read once per round)
+  int active = s->n;
+  auto eval = [&](int initial, bool wide) -> int {
+    const bool bucketed = a.part && active * 8 >= s->n;
+    a.from_parts = bucketed && s->cfg.world <= 1;   // read by the decision kernel that follows
+    if (bucketed) return launch_theta_eval_bucketed(s->st, a, initial);
+    return launch_theta_eval(s->st, a, initial, wide);
+  };
+  GP_TRY(eval(1, many_items));
   GP_TRY(exchange(s));
   s->theta_rounds++;
   GP_TRY(launch_theta_decide(s->st, a, 0));
   std::vector<int> hist((size_t)R + 2, 0);
-  int active = s->n;
   int r = 1;
   while (r <= R) {
     // rounds r .. last run without a look at the counters
     const int last = sharded ? r : min(R, r < 6 ? 6 : r + 2);
     const bool wide = many_items || active * 4 <= s->n;
     for (int q = r; q <= last; ++q) {
-      GP_TRY(launch_theta_eval(s->st, a, 0, wide));
+      GP_TRY(eval(0, wide));
       GP_TRY(exchange(s));
       GP_TRY(launch_theta_decide(s->st, a, q));
     }

@@ -22,6 +22,14 @@ __device__ inline double prior_mean(const double *tpm, int i, int h) {
   return tpm[2 * i] + tpm[2 * i + 1] * (double)(h + 1);
 }
 
+// bucketed evaluation (H = 1): the kernel that fixes the theta to be evaluated next also
+// files the respondent under that theta's grid index
+__device__ inline void bucket_note(const ThetaArgs &a, int i, double th) {
+  const int g = grid_index(th, a.grid_lo, a.grid_step, a.G);
+  a.gidx[i] = g;
+  atomicAdd(&a.ghist[g], 1);
+}
+
 // ellipse draw nu_i = L_t z + s0 z_H + s1 t z_{H+1}, centred state x_i = theta_i - mean_i
 __global__ void theta_prepare_kernel(ThetaArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -38,6 +46,7 @@ __global__ void theta_prepare_kernel(ThetaArgs a) {
     a.xc[i + (int64_t)n * h] = a.theta[i + (int64_t)n * h] - prior_mean(a.tpm, i, h);
   }
   a.done[i] = 0;
+  if (a.part) bucket_note(a, i, a.theta[i]);
 }
 
 int launch_theta_prepare(hipStream_t st, const ThetaArgs &a) {
@@ -107,7 +116,226 @@ __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initia
   }
 }
 
+// Table variant.  A respondent's log-likelihood depends on theta only through the grid index,
+// so with many respondents the G x units x C distinct log cell probabilities are tabulated
+// once per sweep (4 tails and 5 logs per grid point and unit instead of 2 tails per cell and
+// round) and a likelihood evaluation becomes a sum of gathered table entries.
+__global__ __launch_bounds__(256) void theta_table_kernel(ThetaArgs a) {
+  __shared__ double sphi[PHI_LDS_DOUBLES];
+  phi_table_to_lds(sphi);
+  __syncthreads();
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+  const int U_pad = a.U_pad, C = a.C;
+  if (u >= U_pad || u % a.ML >= a.mloc) return;
+  const double xg = a.grid_lo + a.grid_step * g;
+  const double F = a.Gt[u + (int64_t)U_pad * g] + a.betaS[u] + a.betaS[u + U_pad] * xg +
+                   a.betaS[u + 2 * (int64_t)U_pad] * xg * xg;
+  double zlo = -1e30, e1 = phi_upper(1e30, sphi);          // lower end: -inf
+  double *out = a.tab + u + (int64_t)U_pad * C * g;
+  for (int c = 0; c < C; ++c) {
+    const double zhi = c + 1 < C ? fmin(fmax(a.bthrS[u + (int64_t)U_pad * (c + 1)] - F, -1e30), 1e30) : 1e30;
+    const double e2 = phi_upper(fabs(zhi), sphi);
+    out[(int64_t)U_pad * c] = log(ordinal_cell_from_tails(zlo, zhi, e1, e2));
+    zlo = zhi; e1 = e2;
+  }
+}
+
+int launch_theta_table(hipStream_t st, const ThetaArgs &a) {
+  hipLaunchKernelGGL(theta_table_kernel, dim3((a.U_pad + 255) / 256, a.G), dim3(256), 0, st, a);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+template <int WPR>
+__global__ __launch_bounds__(256) void theta_eval_table_kernel(ThetaArgs a, int initial) {
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = WPR == 1 ? blockIdx.x * 4 + w : blockIdx.x;
+  if (i >= a.n) return;
+  if (!initial && a.done[i]) {               // uniform over the workgroup when WPR = 4
+    if (lane == 0 && (WPR == 1 || w == 0)) a.buf[i] = 0.0;
+    return;
+  }
+  const int H = a.H, n = a.n, mloc = a.mloc, ML = a.ML;
+  const int64_t U_pad = a.U_pad;
+  const int jfirst = WPR == 1 ? lane : lane + 64 * w, jstep = 64 * WPR;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (int h = 0; h < H; ++h) {
+    double th = initial ? a.theta[i + (int64_t)n * h]
+                        : a.prop[i + (int64_t)n * h] + prior_mean(a.tpm, i, h);
+    const int g = grid_index(th, a.grid_lo, a.grid_step, a.G);
+    const int p = a.constant_irf ? 0 : h;
+    const double *row = a.tab + U_pad * a.C * g + (int64_t)ML * p;
+    const int8_t *yr = a.yT + (int64_t)ML * H * i + (int64_t)ML * h;
+    int jl = jfirst;
+    for (; jl + 3 * jstep < mloc; jl += 4 * jstep) {      // four independent gathers in flight
+      const int y0 = yr[jl], y1 = yr[jl + jstep], y2 = yr[jl + 2 * jstep], y3 = yr[jl + 3 * jstep];
+      const double v0 = row[jl + U_pad * (max(y0, 1) - 1)];
+      const double v1 = row[jl + jstep + U_pad * (max(y1, 1) - 1)];
+      const double v2 = row[jl + 2 * jstep + U_pad * (max(y2, 1) - 1)];
+      const double v3 = row[jl + 3 * jstep + U_pad * (max(y3, 1) - 1)];
+      s0 += y0 > 0 ? v0 : 0.0; s1 += y1 > 0 ? v1 : 0.0;
+      s2 += y2 > 0 ? v2 : 0.0; s3 += y3 > 0 ? v3 : 0.0;
+    }
+    for (; jl < mloc; jl += jstep) {
+      const int y0 = yr[jl];
+      const double v0 = row[jl + U_pad * (max(y0, 1) - 1)];
+      s0 += y0 > 0 ? v0 : 0.0;
+    }
+  }
+  const double acc = wave_sum((s0 + s1) + (s2 + s3));
+  if (WPR == 1) {
+    if (lane == 0) a.buf[i] = acc;
+  } else {
+    if (lane == 0) red[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) a.buf[i] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// ---- bucketed evaluation (H = 1) -------------------------------------------------------
+// With a workgroup per respondent every evaluation gathers 8 bytes out of each 40..64-byte
+// piece of a 160 KB table row, and respondents at the same grid index re-read the same row
+// from wherever the cache hierarchy still holds it: a round over all respondents moves
+// ~1.6 GB.  Grouped by grid index, a row chunk is read once, kept in LDS, and serves every
+// respondent of its bucket.
+__global__ __launch_bounds__(1024) void theta_bucket_kernel(ThetaArgs a) {
+  __shared__ int hist[THETA_BUCKET_MAX_G];
+  __shared__ int lane_tot[64];
+  const int tid = threadIdx.x, n = a.n, G = a.G;
+  for (int g = tid; g < THETA_BUCKET_MAX_G; g += 1024) {
+    hist[g] = g < G ? a.ghist[g] : 0;
+    if (g < G) a.ghist[g] = 0;                            // ready for the next round's counts
+  }
+  __syncthreads();
+  // exclusive scan by the first wave: each lane owns a run of consecutive bins
+  constexpr int RUN = THETA_BUCKET_MAX_G / 64;
+  if (tid < 64) {
+    int sum = 0;
+    for (int k = 0; k < RUN; ++k) sum += hist[tid * RUN + k];
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (tid >= off) incl += t;
+    }
+    int run = incl - sum;
+    for (int k = 0; k < RUN; ++k) {
+      const int c = hist[tid * RUN + k];
+      hist[tid * RUN + k] = run;
+      run += c;
+    }
+    lane_tot[tid] = incl;
+  }
+  __syncthreads();
+  for (int g = tid; g < G; g += 1024) a.bstart[g] = hist[g];
+  if (tid == 0) a.bstart[G] = lane_tot[63];
+  __syncthreads();
+  constexpr int B = 10;    // respondents per thread and trip: their loads are issued together
+  for (int base = tid; base < n; base += 1024 * B) {
+    int gs[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) gs[b] = a.gidx[min(base + 1024 * b, n - 1)];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const int i = base + 1024 * b;
+      if (i < n && gs[b] >= 0) a.order[atomicAdd(&hist[gs[b]], 1)] = i;   // order inside a bucket is immaterial
+    }
+  }
+}
+
+constexpr int BUCKET_CHUNK_MAX = 1024;   // items per chunk: at most 16 per lane, held in registers
+
+__global__ __launch_bounds__(256) void theta_eval_bucket_kernel(ThetaArgs a) {
+  extern __shared__ double rows[];                        // [C][chunk]
+  const int g = blockIdx.x, ch = blockIdx.y;
+  const int b0 = a.bstart[g], b1 = a.bstart[g + 1];
+  if (b0 >= b1) return;                                   // uniform over the workgroup
+  const int chunk = a.chunk, C = a.C, j0 = ch * chunk, cnt = min(chunk, a.mloc - j0);
+  const int64_t U_pad = a.U_pad;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int PER = BUCKET_CHUNK_MAX / 64, STEP = 4;
+  // a wave per respondent of the bucket.  Two respondents ahead: the respondent's number;
+  // one ahead: the answers; both are in flight while the current table entries are summed.
+  int r = b0 + w;
+  int i0 = a.order[min(r, b1 - 1)], i1 = a.order[min(r + STEP, b1 - 1)];
+  {  // stage the rows: all loads of a thread are issued before the first store
+    const double *src = a.tab + U_pad * C * g + j0;
+    constexpr int LOADS = 6144 / 256;                     // C * chunk <= 6144
+    double tmp[LOADS];
+    const int total = C * chunk;
+#pragma unroll
+    for (int q = 0; q < LOADS; ++q) {
+      const int e = threadIdx.x + 256 * q, c = e / chunk, k = e - c * chunk;
+      tmp[q] = (e < total && k < cnt) ? src[U_pad * c + k] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < LOADS; ++q) {
+      const int e = threadIdx.x + 256 * q;
+      if (e < total) rows[e] = tmp[q];
+    }
+  }
+  int yv[PER], yn[PER];
+  auto load_y = [&](int i, int *dst) {
+    const int8_t *yr = a.yT + (int64_t)a.ML * i + j0;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) dst[t] = yr[min(lane + 64 * t, cnt - 1)];
+  };
+  load_y(i0, yv);
+  __syncthreads();
+  for (; r < b1; r += STEP) {
+    const int i2 = a.order[min(r + 2 * STEP, b1 - 1)];
+    load_y(i1, yn);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int t = 0; t < PER; t += 2) {
+      const int k0 = min(lane + 64 * t, cnt - 1), k1 = min(lane + 64 * (t + 1), cnt - 1);
+      const double v0 = rows[(max(yv[t], 1) - 1) * chunk + k0];
+      const double v1 = rows[(max(yv[t + 1], 1) - 1) * chunk + k1];
+      s0 += (yv[t] > 0 && lane + 64 * t < cnt) ? v0 : 0.0;
+      s1 += (yv[t + 1] > 0 && lane + 64 * (t + 1) < cnt) ? v1 : 0.0;
+    }
+    const double acc = wave_sum(s0 + s1);
+    if (lane == 0) a.part[(int64_t)ch * a.n + i0] = acc;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) yv[t] = yn[t];
+    i0 = i1; i1 = i2;
+  }
+}
+
+__global__ void theta_sum_chunks_kernel(ThetaArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  double s = 0.0;
+  if (a.gidx[i] >= 0)
+    for (int ch = 0; ch < a.nchunks; ++ch) s += a.part[(int64_t)ch * a.n + i];
+  a.buf[i] = s;
+}
+
+// items per chunk: C rows of `chunk` doubles in at most 48 KB of LDS
+int theta_bucket_chunk(int C) { return min(BUCKET_CHUNK_MAX, max(64, (6144 / C) & ~63)); }
+
+int launch_theta_eval_bucketed(hipStream_t st, const ThetaArgs &a, int initial) {
+  if (a.H != 1 || a.G > THETA_BUCKET_MAX_G || !a.tab || !a.part) return GPIRT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(theta_bucket_kernel, dim3(1), dim3(1024), 0, st, a);
+  GP_HIP(hipGetLastError());
+  hipLaunchKernelGGL(theta_eval_bucket_kernel, dim3(a.G, a.nchunks), dim3(256),
+                     sizeof(double) * (size_t)a.C * a.chunk, st, a);
+  GP_HIP(hipGetLastError());
+  if (!a.from_parts) {     // someone other than the decision kernel needs the sums (the exchange)
+    hipLaunchKernelGGL(theta_sum_chunks_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+    GP_HIP(hipGetLastError());
+  }
+  return GPIRT_OK;
+}
+
 int launch_theta_eval(hipStream_t st, const ThetaArgs &a, int initial, bool wide) {
+  if (a.tab) {
+    if (wide) hipLaunchKernelGGL(theta_eval_table_kernel<4>, dim3(a.n), dim3(256), 0, st, a, initial);
+    else hipLaunchKernelGGL(theta_eval_table_kernel<1>, dim3((a.n + 3) / 4), dim3(256), 0, st, a, initial);
+    GP_HIP(hipGetLastError());
+    return GPIRT_OK;
+  }
   if (wide) hipLaunchKernelGGL(theta_eval_kernel<4>, dim3(a.n), dim3(256), 0, st, a, initial);
   else hipLaunchKernelGGL(theta_eval_kernel<1>, dim3((a.n + 3) / 4), dim3(256), 0, st, a, initial);
   GP_HIP(hipGetLastError());
@@ -120,25 +348,33 @@ __global__ void theta_decide_kernel(ThetaArgs a, int round) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   const int H = a.H, n = a.n;
+  double ll;
+  if (a.from_parts) {        // bucketed evaluation: the chunk partials, summed in fixed order
+    ll = 0.0;
+    for (int ch = 0; ch < a.nchunks; ++ch) ll += a.part[(int64_t)ch * n + i];
+  } else {
+    ll = a.buf[i];
+  }
   double phi;
   if (round == 0) {
-    a.hh[i] = log(rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, 0)) + a.buf[i];
+    a.hh[i] = log(rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, 0)) + ll;
     phi = rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, 1) * kTwoPi;
     a.pmin[i] = phi - kTwoPi;
     a.pmax[i] = phi;
   } else {
     if (a.done[i]) return;
-    if (a.buf[i] > a.hh[i]) {
+    if (ll > a.hh[i]) {
       for (int h = 0; h < H; ++h)
         a.theta[i + (int64_t)n * h] = a.prop[i + (int64_t)n * h] + prior_mean(a.tpm, i, h);
       a.done[i] = 1;
+      if (a.part) a.gidx[i] = -1;
       return;
     }
     phi = a.phi[i];
     if (phi > 0.0) a.pmax[i] = phi;
     else if (phi < 0.0) a.pmin[i] = phi;
-    else { a.done[i] = 1; atomicAdd(&a.counters[1], 1ull); return; }
-    if (round >= a.R) { a.done[i] = 1; atomicAdd(&a.counters[1], 1ull); return; }
+    else { a.done[i] = 1; if (a.part) a.gidx[i] = -1; atomicAdd(&a.counters[1], 1ull); return; }
+    if (round >= a.R) { a.done[i] = 1; if (a.part) a.gidx[i] = -1; atomicAdd(&a.counters[1], 1ull); return; }
     double lo = a.pmin[i], hi = a.pmax[i];
     phi = rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, (uint32_t)(1 + round)) * (hi - lo) + lo;
   }
@@ -147,6 +383,7 @@ __global__ void theta_decide_kernel(ThetaArgs a, int round) {
   sincos(phi, &s, &c);
   for (int h = 0; h < H; ++h)
     a.prop[i + (int64_t)n * h] = a.xc[i + (int64_t)n * h] * c + a.nu[i + (int64_t)n * h] * s;
+  if (a.part) bucket_note(a, i, a.prop[i] + prior_mean(a.tpm, i, 0));
   atomicAdd(&a.remaining[round], 1);
 }
 

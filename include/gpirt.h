@@ -63,10 +63,15 @@ enum {
   GPIRT_RETURN_FSTAR = 2,  /* copy each kept draw of f* back (n_grid*m*P doubles per draw)  */
   GPIRT_EXACT_FSTAR = 8,   /* evaluate K(x, xs) at every grid point in the f* step instead of
                               interpolating it from Chebyshev nodes (see gpirt_sampler_sweep)  */
-  GPIRT_ALLREDUCE_ON_STREAM = 4 /* the all-reduce hook ENQUEUES the collective on the sampler's
+  GPIRT_ALLREDUCE_ON_STREAM = 4, /* the all-reduce hook ENQUEUES the collective on the sampler's
                               HIP stream (gpirt_sampler_stream) and returns without waiting;
                               the library then does not drain the stream around the call and
                               looks at the round counters only every few rounds               */
+  GPIRT_THETA_TABLE = 16,  /* respondent slice step: tabulate the log cell probabilities on the
+                              grid once per sweep and sum table entries (default from 1024
+                              respondents on; the flag forces it)                             */
+  GPIRT_THETA_DIRECT = 32  /* respondent slice step: evaluate every cell in every round (default
+                              below 1024 respondents; the flag forces it)                     */
 };
 
 /* Sum-all-reduce hook used by the respondent step when items are sharded over

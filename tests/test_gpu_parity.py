@@ -165,7 +165,10 @@ def _pair(cfg, y, **kw):
 @pytest.mark.parametrize("stem,C,const,flags", [("2PL_C_2", 2, 0, 0), ("Wiener_C_5", 5, 0, 0),
                                                  ("2PL_C_5", 5, 1, 0),
                                                  ("Wiener_C_5", 5, 0, _abi.EXACT_FSTAR),
-                                                 ("2PL_C_5", 5, 1, _abi.EXACT_FSTAR)])
+                                                 ("2PL_C_5", 5, 1, _abi.EXACT_FSTAR),
+                                                 ("2PL_C_2", 2, 0, _abi.THETA_TABLE),
+                                                 ("Wiener_C_5", 5, 0, _abi.THETA_TABLE),
+                                                 ("2PL_C_5", 5, 1, _abi.THETA_TABLE)])
 def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const, flags):
     """Three whole sweeps from the same state with the shared generator: every accept /
     shrink decision must coincide, so the states agree to rounding.  Tolerance 1e-5: f* goes
@@ -192,11 +195,15 @@ def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const, flags):
 
 
 @pytest.mark.parametrize("n,m,sweeps,flags", [(1300, 9, 2, 0), (2100, 5, 1, 0),
-                                              (2100, 5, 1, _abi.EXACT_FSTAR)])
+                                              (2100, 5, 1, _abi.EXACT_FSTAR),
+                                              (1300, 9, 2, _abi.THETA_DIRECT),
+                                              (1100, 2100, 1, 0)])   # two item chunks per table row
 def test_sweep_matches_oracle_wide_units(n, m, sweeps, flags):
     """n >= 1024 rows per unit switches the item kernels to one workgroup per unit and the
     Cholesky to several diagonal blocks (ragged last super-block); n >= 2048 also splits the
-    K range of the f* product into partial sums: same parity bar."""
+    K range of the f* product into partial sums; from 1024 respondents on the respondent step
+    sums entries of the per-sweep table of log cell probabilities unless THETA_DIRECT asks for
+    cell evaluations (the fixtures above force the table with THETA_TABLE): same parity bar."""
     from gpirt_amd.synth import generate
     d = generate(n, m, 3, seed=4)
     cfg = _abi.default_config(n=n, m=m, H=1, C=3, seed=8, flags=flags)
