@@ -331,7 +331,9 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
   double b0, b1, b2;
   params_from_white(v, pm, ps, C, b0, b1, b2, sb);
   if (WPU != 1) __syncthreads();          // the thresholds every wave just wrote (same values)
-  const double cur = ll_param_pass<WPU>(f, x, b0, b1, b2, y, sb, sphi, n, row0, red, w);
+  // the slice update of f that ran just before left the log-likelihood of exactly this state
+  const double cur = a.ll_in ? a.ll_in[u]
+                             : ll_param_pass<WPU>(f, x, b0, b1, b2, y, sb, sphi, n, row0, red, w);
   int r = 0;
   bool ok = false;
   double l = cur;

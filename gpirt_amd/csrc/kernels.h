@@ -47,6 +47,7 @@ struct EssParamArgs {
   int Np, U_pad, C, mloc, ML, m, j0, R;
   uint64_t seed; uint32_t sweep;
   double *ll;
+  const double *ll_in;   // log-likelihood of the current state if the caller has it (else null)
   unsigned long long *counters;
 };
 int launch_ess_param(hipStream_t st, const EssParamArgs &a);

@@ -496,7 +496,7 @@ static int phase_f(gpirt_sampler *s) {
   a.beta = s->d_beta; a.bthr = s->d_bthr; a.unif = nullptr;
   a.Np = s->Np; a.U_pad = s->U_pad; a.C = s->C; a.mloc = s->mloc; a.ML = s->ML; a.m = s->m;
   a.j0 = s->j0; a.R = s->cfg.max_ess_rounds; a.seed = s->seed; a.sweep = s->sweep;
-  a.rounds = nullptr; a.ll = nullptr; a.counters = s->d_counters;
+  a.rounds = nullptr; a.ll = s->d_llu; a.counters = s->d_counters;
   GP_TRY(launch_ess_f(s->st, a));
   return GPIRT_OK;
 }
@@ -510,6 +510,7 @@ static int phase_param(gpirt_sampler *s) {
   a.fixed_thr = s->fixed_thr; a.Np = s->Np; a.U_pad = s->U_pad; a.C = s->C; a.mloc = s->mloc;
   a.ML = s->ML; a.m = s->m; a.j0 = s->j0; a.R = s->cfg.max_ess_rounds; a.seed = s->seed;
   a.sweep = s->sweep; a.ll = s->d_llu; a.counters = s->d_counters + 2;
+  a.ll_in = s->d_llu;       // left by phase_f for the same f, beta and thresholds
   GP_TRY(launch_ess_param(s->st, a));
   return GPIRT_OK;
 }
