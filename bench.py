@@ -195,6 +195,7 @@ def main():
     theta_init = data["theta"] + 0.05 * rng.normal(size=data["theta"].shape)   # gpirt-sythetic.R:86
     cfg = _abi.default_config(n=n, m=m, H=1, C=C, seed=args.seed, theta_os=1.0, theta_ls=1.0,
                               rank=rank, world=world)
+    cfg.flags |= int(os.environ.get("GPIRT_BENCH_FLAGS", "0"))   # e.g. 8 | 32: variants for profiling
     keep = None
     if world > 1:
         cfg.item_begin, cfg.item_end = item_range(m, rank, world)
@@ -237,9 +238,14 @@ def main():
         mloc = (cfg.item_end - cfg.item_begin) if world > 1 else m
         fl = dense_flops(n, mloc, cfg.n_grid)
         # dominant kernel: the FP64 MFMA GEMM; its single largest launch per sweep is
-        # nu = L*Z (phase "nu" is exactly that one launch, timed by HIP events on the
-        # sampler's own stream)
+        # nu = L*Z (phase "nu" is exactly that launch, timed by HIP events on the sampler's own
+        # stream; with few column tiles per GPU -- sharded items -- the launch runs K in slabs
+        # and the phase includes the small kernel that adds them)
         nu_ms = phases["nu"]
+        tiles = -(-n // 128) * -(-mloc // 128)
+        nu_kernel = ("gemm_f64_kernel<false,false,4> (nu = L*Z, one launch per sweep)" if tiles >= 2048 else
+                     "gemm_f64_kernel<false,false,2> (nu = L*Z, one launch per sweep%s)"
+                     % (", K in %d slabs + sum_slabs_kernel" % (8 if tiles < 512 else 4) if tiles < 1024 else ""))
         achieved = fl["nu"] / (nu_ms * 1e-3) / 1e12 if nu_ms > 0 else 0.0
         evals = {k: (d1[k] - d0[k]) / args.steps for k in ("ess_f_rounds", "ess_param_rounds", "ess_theta_rounds")}
         dense_ms = phases["potrf"] + phases["nu"] + phases["fstar"]
@@ -260,7 +266,7 @@ def main():
                                    "1001-point grid, thresholds and beta sampled" % (n, m, C),
                        "items_per_gpu": mloc, "parallelism": "items sharded x%d" % world},
             "roofline": {
-                "kernel": "gemm_f64_kernel<false,false,4> (nu = L*Z, one launch per sweep)",
+                "kernel": nu_kernel,
                 "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                 "flop_per_launch": fl["nu"], "ms_per_launch": nu_ms,

@@ -133,6 +133,8 @@ struct GemmArgs {
   int k_trim;        // 1: A is lower-triangular => K range of row-block bi is [0,(bi+1)*TILE)
                      // 2: A^T is used with A lower-triangular => K range is [bi*TILE, K)
                      // 3: as 1, instantiated under its own kernel name (the nu = L*Z launch)
+  int k_shift;       // k_trim 1 or 3 with the batch index used to split K: slab z holds the K
+                     // columns from z*k_shift on, so its trimmed range ends z*k_shift earlier
 };
 // C = alpha * op(A) * op(B) + beta * C.
 //   AT = false: A(i,k) at A[i + lda*k];  AT = true: A(i,k) at A[k + lda*i]

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
   double *C = g.C + g.strideC * z;   // may alias A or B (in-place panel and solve steps)
   const int i0 = bi * TILE, j0 = bj * TILE;
   int kbeg = 0, kend = g.K;
-  if (MODE == 2 || MODE == 4) kend = min(g.K, (bi + 1) * TILE);
+  if (MODE == 2 || MODE == 4) kend = min(g.K, (bi + 1) * TILE - z * g.k_shift);   // may be <= 0: a zero tile
   if (MODE == 3) kbeg = bi * TILE;
   const int64_t lda = g.lda, ldb = g.ldb;
 
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
       for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
   }
 
+  if (kend > kbeg) {   // uniform over the workgroup
   double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
   TILE_LOAD(AT, A, lda, i0, kbeg, ra);
   TILE_LOAD(!BT, B, ldb, j0, kbeg, rb);
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
       __builtin_amdgcn_sched_barrier(0);
     }
     buf ^= 1;
+  }
   }
 
 #pragma unroll

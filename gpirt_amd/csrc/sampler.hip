@@ -103,6 +103,8 @@ struct gpirt_sampler {
   double *d_llu;
   double *d_onehot, *d_T, *d_lp;   // static (grid) respondent step only
   double *d_tab;                   // slice respondent step, table variant: [U_pad, C, G] (else null)
+  double *d_nuparts;               // partial products of nu = L Z when K is split (else null)
+  int nu_splits;
   double *d_part;                  // bucketed evaluation of the table variant (H = 1, else null)
   int32_t *d_gidx, *d_order, *d_bstart, *d_ghist;
   int th_chunk, th_nchunks;
@@ -129,7 +131,7 @@ static void sampler_free(gpirt_sampler *s) {
                   s->d_pmax, s->d_buf, s->d_Lt, s->d_tpm, s->d_tps, s->d_llu, s->d_done, s->d_info,
                   s->d_remaining, s->d_counters, s->d_onehot, s->d_T, s->d_lp,
                   s->d_sum_th, s->d_sum_th2, s->d_sum_p, s->d_sum_arg, s->d_nodes, s->d_lag, s->d_tab,
-                  s->d_part, s->d_gidx, s->d_order, s->d_bstart, s->d_ghist};
+                  s->d_part, s->d_gidx, s->d_order, s->d_bstart, s->d_ghist, s->d_nuparts};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
   if (s->st) (void)hipStreamDestroy(s->st);
@@ -336,6 +338,19 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   A_(s->d_llu, U_pad);
   A_(s->d_done, n); A_(s->d_info, 1); A_(s->d_remaining, (size_t)(s->cfg.max_ess_rounds + 2));
   A_(s->d_counters, 6);
+  // nu = L Z with few column tiles (a rank's share of the items, or a handful of items): the
+  // longest row panel alone would set the time and most CUs would hold one workgroup or none,
+  // so K is cut into slabs that run side by side.  Measured at n = 10 000: 512 columns
+  // 1.62 -> 1.02 ms with 8 slabs (1.20 with 4), 1024 columns 2.11 -> 1.88 ms with 4 (2 brings
+  // nothing), 2048 columns and more: no gain.
+  s->nu_splits = 1;
+  if (P == 1 && Np_pad >= 1024) {
+    const int tiles = (Np_pad / TILE) * (ML / TILE);
+    int want = tiles < 512 ? 8 : (tiles < 1024 ? 4 : 1);
+    while (want > 1 && (Np_pad / 16) % want) want /= 2;   // slabs: multiples of the GEMM's depth step
+    s->nu_splits = want;
+    if (want > 1) A_(s->d_nuparts, (size_t)want * Np_pad * ML);
+  }
   if (cfg->theta_mode == GPIRT_THETA_GRID) {
     A_(s->d_onehot, (size_t)C * ML * Np_pad);
     A_(s->d_T, (size_t)G_pad * C * ML);
@@ -487,8 +502,21 @@ static int phase_f(gpirt_sampler *s) {
   g.B = s->d_Z; g.ldb = s->Np_pad; g.strideB = (int64_t)s->Np_pad * s->ML;
   g.C = s->d_nu; g.ldc = s->Np_pad; g.strideC = (int64_t)s->Np_pad * s->ML;
   g.M = s->Np_pad; g.N = s->ML; g.K = s->Np_pad; g.batch = s->P; g.alpha = 1.0; g.beta = 0.0;
-  g.k_trim = 3;
-  GP_TRY(launch_gemm(s->st, false, false, g));
+  // the XCD-aware tile order keeps HBM traffic down when there are many column tiles per row
+  // panel; with fewer it is slower than plain longest-first (3.83 vs 3.59 ms at 2048 columns)
+  g.k_trim = (s->Np_pad / TILE) * (s->ML / TILE) >= 2048 ? 3 : 1;
+  if (s->nu_splits > 1) {
+    // the slabs of K run side by side and a small kernel adds them in fixed order
+    const int kc = s->Np_pad / s->nu_splits;
+    g.K = kc; g.k_shift = kc; g.batch = s->nu_splits;
+    g.strideA = (int64_t)kc * s->Np_pad; g.strideB = kc;
+    g.C = s->d_nuparts;
+    GP_TRY(launch_gemm(s->st, false, false, g));
+    GP_TRY(launch_sum_slabs(s->st, s->d_nuparts, s->nu_splits, g.strideC, s->Np_pad, s->ML, s->Np_pad,
+                            s->d_nu, s->Np_pad));
+  } else {
+    GP_TRY(launch_gemm(s->st, false, false, g));
+  }
   GP_TRY(mark(s, PH_ESSF));
   EssFArgs a{};
   a.f = s->d_f; a.nu = s->d_nu; a.ld = s->Np_pad; a.mu = nullptr; a.ld_mu = 0;
