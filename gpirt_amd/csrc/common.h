@@ -173,6 +173,14 @@ int launch_potrs(hipStream_t st, const double *L, const double *inv, int n_pad, 
 int launch_kstar_nodes(hipStream_t st, const double *x, int64_t x_stride, int n, int n_pad, int batch,
                        double ls, double sf, const double *nodes, int R, int R_pad, double *Kc,
                        int64_t group_stride);
+// Pm[r + n_pad*j] = l_j(x_r): barycentric Lagrange basis of the R nodes (weights bw) at the
+// inputs; *outside |= 1 when an input lies outside [lo, hi]
+int launch_bary(hipStream_t st, const double *x, int64_t x_stride, int n, int n_pad, int batch,
+                const double *nodes, const double *bw, int R, double lo, double hi, double *Pm,
+                int64_t group_stride, int *outside);
+// A[(row0+i) + ld*j] = v * (i == j), i, j < TILE
+int launch_scaled_identity(hipStream_t st, double *A, int64_t ld, int row0, int batch, int64_t stride,
+                           double v);
 // out[r + ldo*j] = sum_q x[q*slab_stride + r + ldx*j], rows even (split-K partial results)
 int launch_sum_slabs(hipStream_t st, const double *x, int nslab, int64_t slab_stride, int rows,
                      int cols, int64_t ldx, double *out, int64_t ldo);

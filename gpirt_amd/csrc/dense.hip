@@ -441,6 +441,62 @@ int launch_kstar_nodes(hipStream_t st, const double *x, int64_t x_stride, int n,
   return GPIRT_OK;
 }
 
+// Barycentric Lagrange basis of the Chebyshev nodes at every input: Pm[r + n_pad*j] = l_j(x_r)
+// (rows r >= n zero).  One wave per row.  An input outside [lo, hi] would be extrapolated:
+// it sets *outside instead (the caller then takes another route).
+__global__ __launch_bounds__(256) void bary_kernel(const double *__restrict__ x, int64_t x_stride, int n,
+                                                   int n_pad, const double *__restrict__ nodes,
+                                                   const double *__restrict__ bw, int R, double lo,
+                                                   double hi, double *__restrict__ Pm,
+                                                   int64_t group_stride, int *__restrict__ outside) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6), z = blockIdx.y;
+  if (r >= n_pad) return;
+  double *row = Pm + group_stride * z + r;
+  if (r >= n) {
+    for (int j = lane; j < R; j += 64) row[(int64_t)n_pad * j] = 0.0;
+    return;
+  }
+  const double xr = x[x_stride * z + r];
+  if (!(xr >= lo && xr <= hi) && lane == 0) atomicOr(outside, 1);
+  double den = 0.0;
+  int hit = -1;
+  for (int j = lane; j < R; j += 64) {
+    const double d = xr - nodes[j];
+    if (d == 0.0) hit = j;
+    else den += bw[j] / d;
+  }
+  den = wave_sum(den);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) hit = max(hit, __shfl_xor(hit, off, 64));
+  const double inv = 1.0 / den;
+  for (int j = lane; j < R; j += 64) {
+    const double d = xr - nodes[j];
+    row[(int64_t)n_pad * j] = hit >= 0 ? (j == hit ? 1.0 : 0.0) : (bw[j] / d) * inv;
+  }
+}
+
+int launch_bary(hipStream_t st, const double *x, int64_t x_stride, int n, int n_pad, int batch,
+                const double *nodes, const double *bw, int R, double lo, double hi, double *Pm,
+                int64_t group_stride, int *outside) {
+  hipLaunchKernelGGL(bary_kernel, dim3((n_pad + 3) / 4, batch), dim3(256), 0, st, x, x_stride, n, n_pad,
+                     nodes, bw, R, lo, hi, Pm, group_stride, outside);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// A[(row0 + i) + ld*j] = (i == j) ? v : 0 for i, j < TILE, `batch` groups `stride` apart
+__global__ void scaled_identity_kernel(double *__restrict__ A, int64_t ld, int row0, int64_t stride, double v) {
+  const int i = threadIdx.x, j = blockIdx.x;
+  A[stride * blockIdx.y + row0 + i + ld * j] = i == j ? v : 0.0;
+}
+
+int launch_scaled_identity(hipStream_t st, double *A, int64_t ld, int row0, int batch, int64_t stride,
+                           double v) {
+  hipLaunchKernelGGL(scaled_identity_kernel, dim3(TILE, batch), dim3(TILE), 0, st, A, ld, row0, stride, v);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
 // defined in potrf_diag.hip
 int launch_potrf_diag(hipStream_t st, double *S, int n_pad, int kb, int batch, double *inv_diag, int nb,
                       int *d_info);

@@ -110,6 +110,12 @@ struct gpirt_sampler {
   int th_chunk, th_nchunks;
   double *d_sum_th, *d_sum_th2, *d_sum_p, *d_sum_arg;   // running sums of the summaries (lazy)
   double *d_nodes, *d_lag;   // Chebyshev nodes on the grid's range and the interpolation matrix
+  // low-rank route of the f* step (see setup_fstar_lowrank): barycentric weights, B [R,128],
+  // B^T Lag [128,G_pad]; per sweep Phi [(Np_pad+128),128] per group, its Gram matrix and factor,
+  // X = M^-1 B^T Lag, and the slabs of the Gram product
+  double *d_bw, *d_B, *d_BL, *d_feat, *d_Mm, *d_minv, *d_X, *d_gparts;
+  int fs_lowrank;            // the route is set up
+  int theta_inside;          // this sweep's inputs all lie inside the nodes' range
   int fs_nodes, fs_rank;     // nodes in use and their padded count (0: exact cross-covariance)
   int summary_draws;
   int32_t *d_done, *d_info, *d_remaining;
@@ -131,7 +137,8 @@ static void sampler_free(gpirt_sampler *s) {
                   s->d_pmax, s->d_buf, s->d_Lt, s->d_tpm, s->d_tps, s->d_llu, s->d_done, s->d_info,
                   s->d_remaining, s->d_counters, s->d_onehot, s->d_T, s->d_lp,
                   s->d_sum_th, s->d_sum_th2, s->d_sum_p, s->d_sum_arg, s->d_nodes, s->d_lag, s->d_tab,
-                  s->d_part, s->d_gidx, s->d_order, s->d_bstart, s->d_ghist, s->d_nuparts};
+                  s->d_part, s->d_gidx, s->d_order, s->d_bstart, s->d_ghist, s->d_nuparts,
+                  s->d_bw, s->d_B, s->d_BL, s->d_feat, s->d_Mm, s->d_minv, s->d_X, s->d_gparts};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
   if (s->st) (void)hipStreamDestroy(s->st);
@@ -205,6 +212,130 @@ static int setup_fstar_interpolation(gpirt_sampler *s) {
     return GPIRT_OK;
   }
   s->fs_rank = 0;
+  return GPIRT_OK;
+}
+
+// Eigen-decomposition of a symmetric matrix by cyclic Jacobi rotations (host, set-up only):
+// A [n,n] is overwritten, its diagonal ends as the eigenvalues, V's columns as the vectors.
+static void jacobi_eigen(std::vector<double> &A, int n, std::vector<double> &V) {
+  V.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) V[i + (size_t)n * i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int p = 0; p < n; ++p) {
+      diag += A[p + (size_t)n * p] * A[p + (size_t)n * p];
+      for (int q = p + 1; q < n; ++q) off += A[p + (size_t)n * q] * A[p + (size_t)n * q];
+    }
+    if (off <= 1e-40 * diag) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[p + (size_t)n * q];
+        if (apq == 0.0) continue;
+        const double app = A[p + (size_t)n * p], aqq = A[q + (size_t)n * q];
+        const double tau = (aqq - app) / (2.0 * apq);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+        const double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
+        for (int k = 0; k < n; ++k) {     // columns p, q
+          const double akp = A[k + (size_t)n * p], akq = A[k + (size_t)n * q];
+          A[k + (size_t)n * p] = c * akp - sn * akq;
+          A[k + (size_t)n * q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {     // rows p, q
+          const double apk = A[p + (size_t)n * k], aqk = A[q + (size_t)n * k];
+          A[p + (size_t)n * k] = c * apk - sn * aqk;
+          A[q + (size_t)n * k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = V[k + (size_t)n * p], vkq = V[k + (size_t)n * q];
+          V[k + (size_t)n * p] = c * vkp - sn * vkq;
+          V[k + (size_t)n * q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+}
+
+// Low-rank route of the f* step.  With l(x) the Lagrange basis of the Chebyshev nodes c and
+// Kcc = K(c, c), the kernel is reproduced to rounding level in BOTH arguments,
+//   K(x, x') = l(x)^T Kcc l(x'),
+// so with Kcc = V D V^T (eigenvalues below 1e-17 of the largest dropped), B = V D^1/2 and
+// Phi = P B (P = the basis at the inputs):  S = K(x,x) + s2 I = Phi Phi^T + s2 I,
+// K(xs, x) = (B^T Lag)^T Phi^T, and by the push-through identity
+//   f*^T = F^T S^-1 K(x, xs) = (F^T Phi) (s2 I + Phi^T Phi)^-1 (B^T Lag):
+// one [units x n x 128] product and a 128 x 128 factorisation replace the two triangular
+// solves with the n x n factor.  Everything that depends only on the nodes is built here.
+static int setup_fstar_lowrank(gpirt_sampler *s) {
+  s->fs_lowrank = 0;
+  const int R = s->fs_rank, G = s->G, G_pad = s->G_pad;
+  if (R <= 0) return GPIRT_OK;
+  const double lo = s->cfg.grid_lo, hi = lo + s->cfg.grid_step * (G - 1);
+  const double ls = s->cfg.irf_ls, sf2 = s->cfg.irf_sf * s->cfg.irf_sf;
+  std::vector<double> c(R), w(R), lag((size_t)R * G_pad);
+  GP_HIP(hipMemcpy(c.data(), s->d_nodes, sizeof(double) * R, hipMemcpyDeviceToHost));
+  GP_HIP(hipMemcpy(lag.data(), s->d_lag, sizeof(double) * lag.size(), hipMemcpyDeviceToHost));
+  for (int j = 0; j < R; ++j) w[j] = (j & 1) ? -1.0 : 1.0;
+  w[0] *= 0.5; w[R - 1] *= 0.5;
+  std::vector<double> Kcc((size_t)R * R), V;
+  for (int a = 0; a < R; ++a)
+    for (int b = 0; b < R; ++b) Kcc[a + (size_t)R * b] = sf2 * exp(-0.5 * (c[a] - c[b]) * (c[a] - c[b]) / (ls * ls));
+  std::vector<double> A = Kcc;
+  jacobi_eigen(A, R, V);
+  double dmax = 0.0;
+  for (int k = 0; k < R; ++k) dmax = fmax(dmax, A[k + (size_t)R * k]);
+  std::vector<int> keep;
+  for (int k = 0; k < R; ++k)
+    if (A[k + (size_t)R * k] > 1e-17 * dmax) keep.push_back(k);
+  if ((int)keep.size() > TILE) return GPIRT_OK;            // kernel too rough for 128 columns
+  std::vector<double> B((size_t)R * TILE, 0.0);             // [R, 128], zero columns beyond the rank
+  for (size_t q = 0; q < keep.size(); ++q) {
+    const double sd = sqrt(A[keep[q] + (size_t)R * keep[q]]);
+    for (int a = 0; a < R; ++a) B[a + (size_t)R * q] = V[a + (size_t)R * keep[q]] * sd;
+  }
+  // check: l(x)^T B B^T l(x') against the kernel on a lattice of the range
+  double err = 0.0;
+  const int T = 48;
+  std::vector<double> PB((size_t)T * TILE);
+  std::vector<double> xt(T);
+  for (int t = 0; t < T; ++t) {
+    xt[t] = lo + (hi - lo) * (t + 0.37) / T;
+    std::vector<double> l(R);
+    double den = 0.0;
+    for (int j = 0; j < R; ++j) den += w[j] / (xt[t] - c[j]);
+    for (int j = 0; j < R; ++j) l[j] = (w[j] / (xt[t] - c[j])) / den;
+    for (int q = 0; q < TILE; ++q) {
+      double acc = 0.0;
+      for (int j = 0; j < R; ++j) acc += l[j] * B[j + (size_t)R * q];
+      PB[t + (size_t)T * q] = acc;
+    }
+  }
+  for (int t = 0; t < T; ++t)
+    for (int u = 0; u < T; ++u) {
+      double acc = 0.0;
+      for (int q = 0; q < TILE; ++q) acc += PB[t + (size_t)T * q] * PB[u + (size_t)T * q];
+      err = fmax(err, fabs(acc - sf2 * exp(-0.5 * (xt[t] - xt[u]) * (xt[t] - xt[u]) / (ls * ls))));
+    }
+  if (err > 1e-12 * sf2) return GPIRT_OK;
+  std::vector<double> BL((size_t)TILE * G_pad, 0.0);        // [128, G_pad] = B^T Lag
+  for (int g = 0; g < G; ++g)
+    for (int q = 0; q < (int)keep.size(); ++q) {
+      double acc = 0.0;
+      for (int j = 0; j < R; ++j) acc += B[j + (size_t)R * q] * lag[j + (size_t)R * g];
+      BL[q + (size_t)TILE * g] = acc;
+    }
+  const int64_t ldp = s->Np_pad + TILE;
+  GP_TRY(dalloc(s->d_bw, (size_t)R));
+  GP_TRY(dalloc(s->d_B, B.size()));
+  GP_TRY(dalloc(s->d_BL, BL.size()));
+  GP_TRY(dalloc(s->d_feat, (size_t)ldp * TILE * s->P));
+  GP_TRY(dalloc(s->d_Mm, (size_t)TILE * TILE * s->P));
+  GP_TRY(dalloc(s->d_minv, (size_t)inv_group_elems(TILE) * s->P));
+  GP_TRY(dalloc(s->d_X, (size_t)TILE * G_pad * s->P));
+  GP_TRY(dalloc(s->d_gparts, (size_t)(ldp / TILE) * TILE * TILE));
+  GP_HIP(hipMemcpy(s->d_bw, w.data(), sizeof(double) * R, hipMemcpyHostToDevice));
+  GP_HIP(hipMemcpy(s->d_B, B.data(), sizeof(double) * B.size(), hipMemcpyHostToDevice));
+  GP_HIP(hipMemcpy(s->d_BL, BL.data(), sizeof(double) * BL.size(), hipMemcpyHostToDevice));
+  GP_HIP(hipMemset(s->d_feat, 0, sizeof(double) * (size_t)ldp * TILE * s->P));
+  GP_HIP(hipMemset(s->d_minv, 0, sizeof(double) * (size_t)inv_group_elems(TILE) * s->P));
+  s->fs_lowrank = 1;
   return GPIRT_OK;
 }
 
@@ -336,7 +467,7 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   A_(s->d_Lt, (size_t)H * H);
   A_(s->d_tpm, 2 * (size_t)n); A_(s->d_tps, 2 * (size_t)n);
   A_(s->d_llu, U_pad);
-  A_(s->d_done, n); A_(s->d_info, 1); A_(s->d_remaining, (size_t)(s->cfg.max_ess_rounds + 2));
+  A_(s->d_done, n); A_(s->d_info, 3); A_(s->d_remaining, (size_t)(s->cfg.max_ess_rounds + 2));
   A_(s->d_counters, 6);
   // nu = L Z with few column tiles (a rank's share of the items, or a handful of items): the
   // longest row panel alone would set the time and most CUs would hold one workgroup or none,
@@ -432,6 +563,7 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
 #undef UP_
   if (!(cfg->flags & GPIRT_EXACT_FSTAR)) {
     if ((rc = setup_fstar_interpolation(s))) return fail(rc);
+    if (!(cfg->flags & GPIRT_FSTAR_SOLVE) && (rc = setup_fstar_lowrank(s))) return fail(rc);
   }
   if (cfg->theta_mode == GPIRT_THETA_GRID) {
     if ((rc = launch_grid_onehot(s->st, s->d_yT, n, mloc, ML, C, s->d_onehot))) return fail(rc);
@@ -477,11 +609,24 @@ static int phase_factor(gpirt_sampler *s) {
     GP_TRY(launch_k_build(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
                           s->cfg.irf_sf, s->jitter_now, s->d_S, false));
     GP_TRY(mark(s, PH_POTRF));
-    GP_HIP(hipMemsetAsync(s->d_info, 0, sizeof(int), s->st));
+    // info[0]: pivot of a failed factorisation; [1]: an input outside the range of the f*
+    // nodes; [2]: the 128 x 128 factorisation of the previous sweep's low-rank f* step
+    int info3[3] = {0, 0, 0};
+    GP_HIP(hipMemcpyAsync(info3 + 2, s->d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    GP_HIP(hipMemsetAsync(s->d_info, 0, 3 * sizeof(int), s->st));
+    if (s->fs_lowrank)   // the Lagrange basis at the inputs; it waits in W, which is free until the f* step
+      GP_TRY(launch_bary(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->d_nodes, s->d_bw, s->fs_nodes,
+                         s->cfg.grid_lo, s->cfg.grid_lo + s->cfg.grid_step * (s->G - 1), s->d_W,
+                         (int64_t)s->Np_pad * s->G_pad, s->d_info + 1));
     GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info, s->d_fwork));
-    int info = 0;
-    GP_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    GP_HIP(hipMemcpyAsync(info3, s->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, s->st));
     GP_HIP(hipStreamSynchronize(s->st));
+    if (info3[2]) {
+      set_error("low-rank f* step: s2 I + Phi^T Phi is not positive definite (pivot %d)", info3[2]);
+      return GPIRT_ERR_NOT_PD;
+    }
+    s->theta_inside = !info3[1];
+    const int info = info3[0];
     if (!info) return GPIRT_OK;
     if (s->jitter_now >= 1e-2) {
       set_error("K(theta,theta)+%g I is not positive definite (pivot %d)", s->jitter_now, info);
@@ -552,16 +697,48 @@ static int phase_fstar(gpirt_sampler *s) {
   if (s->fs_rank > 0) {
     // interpolated cross-covariance: solve for the R node columns only,
     //   Y = F^T S^-1 K(x, c)   [units x R],   f*^T = Y Lag   [units x G]
-    const int R = s->fs_rank;
-    GP_TRY(launch_kstar_nodes(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
-                              s->cfg.irf_sf, s->d_nodes, s->fs_nodes, R, s->d_W,
-                              (int64_t)s->Np_pad * s->G_pad));
-    GP_TRY(launch_potrs(s->st, s->d_S, s->d_inv, s->Np_pad, s->P, s->d_W, s->Np_pad,
-                        (int64_t)s->Np_pad * s->G_pad, R, s->d_xtmp));
+    int R = s->fs_rank;
+    const bool lowrank = s->fs_lowrank && s->theta_inside;
+    const int64_t ldp = s->Np_pad + TILE;
+    if (lowrank) {
+      // f*^T = (F^T Phi) (s2 I + Phi^T Phi)^-1 (B^T Lag), see setup_fstar_lowrank.
+      // Phi = P B, with sqrt(s2) I appended below so that its Gram matrix carries the s2 I
+      GemmArgs a{};
+      a.A = s->d_W; a.lda = s->Np_pad; a.strideA = (int64_t)s->Np_pad * s->G_pad;
+      a.B = s->d_B; a.ldb = s->fs_nodes; a.strideB = 0;
+      a.C = s->d_feat; a.ldc = ldp; a.strideC = ldp * TILE;
+      a.M = s->Np_pad; a.N = TILE; a.K = s->fs_nodes; a.batch = s->P; a.alpha = 1.0; a.beta = 0.0;
+      GP_TRY(launch_gemm(s->st, false, false, a));
+      GP_TRY(launch_scaled_identity(s->st, s->d_feat, ldp, s->Np_pad, s->P, ldp * TILE, sqrt(s->jitter_now)));
+      const int nslab = (int)(ldp / TILE);
+      for (int p = 0; p < s->P; ++p) {     // M = Phi^T Phi, K in 128-deep slabs side by side
+        GemmArgs m{};
+        m.A = s->d_feat + ldp * TILE * p; m.lda = ldp; m.strideA = TILE;
+        m.B = m.A; m.ldb = ldp; m.strideB = TILE;
+        m.C = s->d_gparts; m.ldc = TILE; m.strideC = TILE * TILE;
+        m.M = TILE; m.N = TILE; m.K = TILE; m.batch = nslab; m.alpha = 1.0; m.beta = 0.0;
+        GP_TRY(launch_gemm(s->st, true, false, m));
+        GP_TRY(launch_sum_slabs(s->st, s->d_gparts, nslab, TILE * TILE, TILE, TILE, TILE,
+                                s->d_Mm + (int64_t)TILE * TILE * p, TILE));
+        GP_HIP(hipMemcpyAsync(s->d_X + (int64_t)TILE * s->G_pad * p, s->d_BL,
+                              sizeof(double) * (size_t)TILE * s->G_pad, hipMemcpyDeviceToDevice, s->st));
+      }
+      GP_TRY(launch_potrf(s->st, s->d_Mm, TILE, s->P, s->d_minv, s->d_info + 2, s->d_fwork));
+      GP_TRY(launch_potrs(s->st, s->d_Mm, s->d_minv, TILE, s->P, s->d_X, TILE, (int64_t)TILE * s->G_pad,
+                          s->G_pad, s->d_xtmp));
+      R = TILE;
+    } else {
+      GP_TRY(launch_kstar_nodes(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
+                                s->cfg.irf_sf, s->d_nodes, s->fs_nodes, R, s->d_W,
+                                (int64_t)s->Np_pad * s->G_pad));
+      GP_TRY(launch_potrs(s->st, s->d_S, s->d_inv, s->Np_pad, s->P, s->d_W, s->Np_pad,
+                          (int64_t)s->Np_pad * s->G_pad, R, s->d_xtmp));
+    }
     double *Y = s->d_nu;          // [U_pad, R], free between the f step and the next sweep
     GemmArgs g{};
     g.A = s->d_f; g.lda = s->Np_pad; g.strideA = (int64_t)s->Np_pad * s->ML;
     g.B = s->d_W; g.ldb = s->Np_pad; g.strideB = (int64_t)s->Np_pad * s->G_pad;
+    if (lowrank) { g.B = s->d_feat; g.ldb = ldp; g.strideB = ldp * TILE; }
     g.C = Y; g.ldc = s->U_pad; g.strideC = s->ML;
     g.M = s->ML; g.N = R; g.K = s->Np_pad; g.batch = s->P; g.alpha = 1.0; g.beta = 0.0;
     const int64_t tiles = (int64_t)(s->ML / TILE) * (R / TILE);
@@ -584,6 +761,7 @@ static int phase_fstar(gpirt_sampler *s) {
     GemmArgs h{};
     h.A = Y; h.lda = s->U_pad; h.strideA = s->ML;
     h.B = s->d_lag; h.ldb = R; h.strideB = 0;
+    if (lowrank) { h.B = s->d_X; h.ldb = TILE; h.strideB = (int64_t)TILE * s->G_pad; }
     h.C = s->d_Gt; h.ldc = s->U_pad; h.strideC = s->ML;
     h.M = s->ML; h.N = s->G_pad; h.K = R; h.batch = s->P; h.alpha = 1.0; h.beta = 0.0;
     GP_TRY(launch_gemm(s->st, false, false, h));

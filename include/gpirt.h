@@ -70,8 +70,11 @@ enum {
   GPIRT_THETA_TABLE = 16,  /* respondent slice step: tabulate the log cell probabilities on the
                               grid once per sweep and sum table entries (default from 1024
                               respondents on; the flag forces it)                             */
-  GPIRT_THETA_DIRECT = 32  /* respondent slice step: evaluate every cell in every round (default
+  GPIRT_THETA_DIRECT = 32, /* respondent slice step: evaluate every cell in every round (default
                               below 1024 respondents; the flag forces it)                     */
+  GPIRT_FSTAR_SOLVE = 64   /* f* step: keep the interpolated cross-covariance but go through the
+                              two triangular solves with the n x n factor instead of the low-rank
+                              identity (see gpirt_sampler_sweep)                              */
 };
 
 /* Sum-all-reduce hook used by the respondent step when items are sharded over
@@ -187,7 +190,17 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
                          const double *theta_prior_means, const double *theta_prior_sds,
                          const double *thresholds, gpirt_sampler **out);
 /* Advance `sweeps` Gibbs sweeps (main.m:46-87 body).  Asynchronous work is drained
- * before return. */
+ * before return.
+ *
+ * The f* step (main.m:57-58, f* = K(xs, x) [K(x, x) + s2 I]^-1 f) has three routes that agree
+ * to the accuracy the condition of K(x, x) + s2 I allows (about 1e-6 of |f*| at n = 10 000):
+ *   default            the kernel is reproduced to rounding level from 128 Chebyshev nodes in
+ *                      both arguments, K(x, x') = l(x)^T K(c, c) l(x'), which turns the step
+ *                      into one [units x n x 128] product and a 128 x 128 factorisation; used
+ *                      while every input lies on the grid's range, else FSTAR_SOLVE's route;
+ *   GPIRT_FSTAR_SOLVE  K(x, xs) = K(x, c) Lag interpolated in the grid argument only, two
+ *                      triangular solves with the n x n factor for the 128 node columns;
+ *   GPIRT_EXACT_FSTAR  K(x, xs) evaluated at every grid point, solves for all columns. */
 int gpirt_sampler_sweep(gpirt_sampler *s, int32_t sweeps);
 /* Copy the current state to host buffers (any may be NULL):
  * theta [n,H]; f [n,m_loc,H]; fstar [n_grid,m_loc,P]; beta [3,m_loc,P];

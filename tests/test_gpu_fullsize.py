@@ -96,13 +96,13 @@ def test_loglik_checksum_of_checksums_and_additivity(K):
     assert np.array_equal(lr_b[N // 2:], lr[N // 2:]) and not lr_b[:N // 2].any()
 
 
-@pytest.mark.parametrize("flags", [0, _abi.EXACT_FSTAR, _abi.THETA_DIRECT])
+@pytest.mark.parametrize("flags", [0, _abi.EXACT_FSTAR, _abi.THETA_DIRECT, _abi.FSTAR_SOLVE])
 def test_sweep_invariants(flags):
     """Two sweeps of the benchmark configuration.  Whatever was drawn: thresholds stay ordered
     with infinite ends, no slice update ran into the round cap, f was re-anchored on the grid
     curve at each respondent's new theta (main.m:69-73), and the variants of two steps lead to
-    the same chain: interpolated / exact cross-covariance in the f* step (main.m:57-58), and in
-    the respondent step table rows served per grid index / every cell evaluated in every round."""
+    the same chain: low-rank identity / triangular solves with interpolated / exact
+    cross-covariance in the f* step (main.m:57-58), and in the respondent step table rows served per grid index / every cell evaluated in every round."""
     from gpirt_amd.sampler import Sampler
     from gpirt_amd.synth import generate
     d = generate(N, M, C, seed=1)

@@ -166,6 +166,8 @@ def _pair(cfg, y, **kw):
                                                  ("2PL_C_5", 5, 1, 0),
                                                  ("Wiener_C_5", 5, 0, _abi.EXACT_FSTAR),
                                                  ("2PL_C_5", 5, 1, _abi.EXACT_FSTAR),
+                                                 ("Wiener_C_5", 5, 0, _abi.FSTAR_SOLVE),
+                                                 ("2PL_C_5", 5, 1, _abi.FSTAR_SOLVE),
                                                  ("2PL_C_2", 2, 0, _abi.THETA_TABLE),
                                                  ("Wiener_C_5", 5, 0, _abi.THETA_TABLE),
                                                  ("2PL_C_5", 5, 1, _abi.THETA_TABLE)])
@@ -196,6 +198,7 @@ def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const, flags):
 
 @pytest.mark.parametrize("n,m,sweeps,flags", [(1300, 9, 2, 0), (2100, 5, 1, 0),
                                               (2100, 5, 1, _abi.EXACT_FSTAR),
+                                              (2100, 5, 1, _abi.FSTAR_SOLVE),
                                               (1300, 9, 2, _abi.THETA_DIRECT),
                                               (1100, 2100, 1, 0)])   # two item chunks per table row
 def test_sweep_matches_oracle_wide_units(n, m, sweeps, flags):
@@ -219,11 +222,12 @@ def test_sweep_matches_oracle_wide_units(n, m, sweeps, flags):
     g.close(); c.close()
 
 
-@pytest.mark.parametrize("flags", [0, _abi.EXACT_FSTAR])
+@pytest.mark.parametrize("flags", [0, _abi.EXACT_FSTAR, _abi.FSTAR_SOLVE])
 def test_sweep_matches_oracle_many_items(flags):
     """More unit columns than grid points (ML >= G_pad = 1024): with the exact cross-covariance
-    the f* phase then solves S^-1 K(x, xs) instead of S^-1 F; by default it solves for the
-    Chebyshev-node columns only.  Same parity bar."""
+    the f* phase then solves S^-1 K(x, xs) instead of S^-1 F; with FSTAR_SOLVE it solves for the
+    Chebyshev-node columns only; by default it takes the low-rank identity and solves nothing
+    with the n x n factor.  Same parity bar."""
     from gpirt_amd.synth import generate
     d = generate(70, 1030, 3, seed=6)
     cfg = _abi.default_config(n=70, m=1030, H=1, C=3, seed=2, flags=flags)
