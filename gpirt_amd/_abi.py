@@ -21,6 +21,7 @@ EXACT_FSTAR = 8
 THETA_TABLE = 16
 THETA_DIRECT = 32
 FSTAR_SOLVE = 64
+GENERATOR_PRIOR = 128
 
 # stream tags of the counter-based generator (same values in both backends)
 TAG_F_Z, TAG_F_U, TAG_P_Z, TAG_P_U, TAG_T_Z, TAG_T_U, TAG_INIT = 1, 2, 3, 4, 5, 6, 7

@@ -181,6 +181,12 @@ int launch_bary(hipStream_t st, const double *x, int64_t x_stride, int n, int n_
 // A[(row0+i) + ld*j] = v * (i == j), i, j < TILE
 int launch_scaled_identity(hipStream_t st, double *A, int64_t ld, int row0, int batch, int64_t stride,
                            double v);
+// J[b] = s2 I + slabs[0] + ... + slabs[b-1], TILE x TILE blocks (b < nblk)
+int launch_prefix_gram(hipStream_t st, const double *slabs, int nblk, double s2, double *J);
+// zero above the diagonal of `batch` TILE x TILE blocks
+int launch_tril(hipStream_t st, double *A, int batch);
+// in place: block b <- sum of the blocks before it (blocks of `elems` doubles, elems even)
+int launch_prefix_blocks(hipStream_t st, double *V, int64_t elems, int nblk);
 // out[r + ldo*j] = sum_q x[q*slab_stride + r + ldx*j], rows even (split-K partial results)
 int launch_sum_slabs(hipStream_t st, const double *x, int nslab, int64_t slab_stride, int rows,
                      int cols, int64_t ldx, double *out, int64_t ldo);

@@ -497,6 +497,56 @@ int launch_scaled_identity(hipStream_t st, double *A, int64_t ld, int row0, int 
   return GPIRT_OK;
 }
 
+// J[b] = s2 I + sum of the Gram slabs of the blocks before b (exclusive prefix over b), TILE x TILE each
+__global__ void prefix_gram_kernel(const double *__restrict__ slabs, int nblk, double s2,
+                                   double *__restrict__ J) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;      // element of a TILE x TILE block
+  const double d = (e % TILE == e / TILE) ? s2 : 0.0;
+  double acc = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    J[(int64_t)TILE * TILE * b + e] = acc + d;
+    acc += slabs[(int64_t)TILE * TILE * b + e];
+  }
+}
+
+int launch_prefix_gram(hipStream_t st, const double *slabs, int nblk, double s2, double *J) {
+  hipLaunchKernelGGL(prefix_gram_kernel, dim3(TILE * TILE / 256), dim3(256), 0, st, slabs, nblk, s2, J);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// zero above the diagonal of `batch` TILE x TILE blocks (ld = TILE)
+__global__ void tril_kernel(double *__restrict__ A) {
+  const int i = threadIdx.x, j = blockIdx.x;
+  if (i < j) A[(int64_t)TILE * TILE * blockIdx.y + i + TILE * j] = 0.0;
+}
+
+int launch_tril(hipStream_t st, double *A, int batch) {
+  hipLaunchKernelGGL(tril_kernel, dim3(TILE, batch), dim3(TILE), 0, st, A);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// in place, over nblk consecutive blocks of `elems` doubles: V[b] <- V[0] + ... + V[b-1]
+__global__ void prefix_blocks_kernel(double *__restrict__ V, int64_t elems, int nblk) {
+  const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (e >= elems) return;
+  double2 acc = make_double2(0.0, 0.0);
+  for (int b = 0; b < nblk; ++b) {
+    double2 *p = reinterpret_cast<double2 *>(V + elems * b + e);
+    const double2 v = *p;
+    *p = acc;
+    acc.x += v.x; acc.y += v.y;
+  }
+}
+
+int launch_prefix_blocks(hipStream_t st, double *V, int64_t elems, int nblk) {
+  hipLaunchKernelGGL(prefix_blocks_kernel, dim3((unsigned)((elems / 2 + 255) / 256)), dim3(256), 0, st, V,
+                     elems, nblk);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
 // defined in potrf_diag.hip
 int launch_potrf_diag(hipStream_t st, double *S, int n_pad, int kb, int batch, double *inv_diag, int nb,
                       int *d_info);

@@ -115,6 +115,12 @@ struct gpirt_sampler {
   // X = M^-1 B^T Lag, and the slabs of the Gram product
   double *d_bw, *d_B, *d_BL, *d_feat, *d_Mm, *d_minv, *d_X, *d_gparts;
   int fs_lowrank;            // the route is set up
+  // generator form of the prior factor (GPIRT_GENERATOR_PRIOR, see phase_factor_generator):
+  // per 128-row block b the factors R_b of J_b and L_bb of the block's Schur complement with
+  // their inverses, T_b, L_bb^-1 T_b, W_b^T, and the per-block partial products of nu
+  double *d_Jb, *d_jinv, *d_Tb, *d_Sbb, *d_linv, *d_Et, *d_Wt, *d_V;
+  int gen_prior;             // the route is set up
+  int gen_now;               // this sweep's factor is in generator form
   int theta_inside;          // this sweep's inputs all lie inside the nodes' range
   int fs_nodes, fs_rank;     // nodes in use and their padded count (0: exact cross-covariance)
   int summary_draws;
@@ -138,7 +144,8 @@ static void sampler_free(gpirt_sampler *s) {
                   s->d_remaining, s->d_counters, s->d_onehot, s->d_T, s->d_lp,
                   s->d_sum_th, s->d_sum_th2, s->d_sum_p, s->d_sum_arg, s->d_nodes, s->d_lag, s->d_tab,
                   s->d_part, s->d_gidx, s->d_order, s->d_bstart, s->d_ghist, s->d_nuparts,
-                  s->d_bw, s->d_B, s->d_BL, s->d_feat, s->d_Mm, s->d_minv, s->d_X, s->d_gparts};
+                  s->d_bw, s->d_B, s->d_BL, s->d_feat, s->d_Mm, s->d_minv, s->d_X, s->d_gparts,
+                  s->d_Jb, s->d_jinv, s->d_Tb, s->d_Sbb, s->d_linv, s->d_Et, s->d_Wt, s->d_V};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
   if (s->st) (void)hipStreamDestroy(s->st);
@@ -339,6 +346,23 @@ static int setup_fstar_lowrank(gpirt_sampler *s) {
   return GPIRT_OK;
 }
 
+// Buffers of the generator form of the prior factor (one IRF group only).
+static int setup_generator_prior(gpirt_sampler *s) {
+  s->gen_prior = 0;
+  if (!s->fs_lowrank || s->P != 1) return GPIRT_OK;
+  const size_t nblk = (size_t)s->Np_pad / TILE, blk = (size_t)TILE * TILE;
+  GP_TRY(dalloc(s->d_Jb, nblk * blk));
+  GP_TRY(dalloc(s->d_jinv, nblk * (size_t)inv_group_elems(TILE)));
+  GP_TRY(dalloc(s->d_Tb, nblk * blk));
+  GP_TRY(dalloc(s->d_Sbb, nblk * blk));
+  GP_TRY(dalloc(s->d_linv, nblk * (size_t)inv_group_elems(TILE)));
+  GP_TRY(dalloc(s->d_Et, nblk * blk));
+  GP_TRY(dalloc(s->d_Wt, nblk * blk));
+  GP_TRY(dalloc(s->d_V, (size_t)s->Np_pad * s->ML));
+  s->gen_prior = 1;
+  return GPIRT_OK;
+}
+
 static int check_cfg(const gpirt_config *cfg) {
   if (!cfg) { set_error("cfg is NULL"); return GPIRT_ERR_BAD_ARG; }
   if (cfg->struct_size != (int32_t)sizeof(gpirt_config)) {
@@ -361,6 +385,11 @@ static int check_cfg(const gpirt_config *cfg) {
   }
   if (cfg->theta_mode == GPIRT_THETA_GRID && cfg->H != 1) {
     set_error("GPIRT_THETA_GRID is the static respondent step: H must be 1 (got %d)", cfg->H);
+    return GPIRT_ERR_BAD_ARG;
+  }
+  if ((cfg->flags & GPIRT_GENERATOR_PRIOR) && (cfg->flags & (GPIRT_EXACT_FSTAR | GPIRT_FSTAR_SOLVE))) {
+    set_error("GPIRT_GENERATOR_PRIOR keeps no dense factor: it cannot be combined with the f* routes "
+              "that solve with it (GPIRT_EXACT_FSTAR, GPIRT_FSTAR_SOLVE)");
     return GPIRT_ERR_BAD_ARG;
   }
   if (cfg->world > 1 && !cfg->allreduce) {
@@ -564,6 +593,7 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   if (!(cfg->flags & GPIRT_EXACT_FSTAR)) {
     if ((rc = setup_fstar_interpolation(s))) return fail(rc);
     if (!(cfg->flags & GPIRT_FSTAR_SOLVE) && (rc = setup_fstar_lowrank(s))) return fail(rc);
+    if ((cfg->flags & GPIRT_GENERATOR_PRIOR) && (rc = setup_generator_prior(s))) return fail(rc);
   }
   if (cfg->theta_mode == GPIRT_THETA_GRID) {
     if ((rc = launch_grid_onehot(s->st, s->d_yT, n, mloc, ML, C, s->d_onehot))) return fail(rc);
@@ -603,7 +633,89 @@ static int collect_times(gpirt_sampler *s) {
   return GPIRT_OK;
 }
 
+// Generator form of the prior factor.  With S = Phi Phi^T + s2 I (setup_fstar_lowrank) the
+// Cholesky factor is block semiseparable: for the 128-row blocks b, with G_b the Gram matrix
+// of the rows of Phi before block b and J_b = s2 I + G_b = R_b R_b^T,
+//   T_b = s Phi_b R_b^-T,   L_bb L_bb^T = s2 I + T_b T_b^T   (the block's Schur complement),
+//   L_ib = Phi_i W_b for every later row i,   W_b^T = s (L_bb^-1 T_b) R_b^-1,
+// so that  nu = L z  is  nu_b = L_bb z_b + Phi_b sum_{b' < b} W_b' z_b'  (chol(K)'*z of
+// sample_fs.m:2, demo.m:45, without the n x n matrix).  All blocks are independent given the
+// prefix sums: the two factorisations run as batches of the diagonal kernel.  *done = 0 when
+// an input lies outside the nodes' range; the caller then takes the dense route for this sweep.
+static int phase_factor_generator(gpirt_sampler *s, int *done) {
+  *done = 0;
+  GP_TRY(mark(s, PH_KBUILD));
+  int info3[3] = {0, 0, 0};
+  GP_HIP(hipMemcpyAsync(info3 + 2, s->d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s->st));
+  GP_HIP(hipMemsetAsync(s->d_info, 0, 3 * sizeof(int), s->st));
+  GP_TRY(launch_bary(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->d_nodes, s->d_bw, s->fs_nodes,
+                     s->cfg.grid_lo, s->cfg.grid_lo + s->cfg.grid_step * (s->G - 1), s->d_W,
+                     (int64_t)s->Np_pad * s->G_pad, s->d_info + 1));
+  GP_HIP(hipMemcpyAsync(info3 + 1, s->d_info + 1, sizeof(int), hipMemcpyDeviceToHost, s->st));
+  GP_HIP(hipStreamSynchronize(s->st));
+  if (info3[2]) {
+    set_error("low-rank f* step: s2 I + Phi^T Phi is not positive definite (pivot %d)", info3[2]);
+    return GPIRT_ERR_NOT_PD;
+  }
+  if (info3[1]) return GPIRT_OK;
+  s->theta_inside = 1;
+  GP_TRY(mark(s, PH_POTRF));
+  const int nblk = s->Np_pad / TILE;
+  const int64_t ldp = s->Np_pad + TILE, blk = (int64_t)TILE * TILE, sI = inv_group_elems(TILE);
+  const double s2 = s->jitter_now, sd = sqrt(s2);
+  GemmArgs a{};   // Phi = P B
+  a.A = s->d_W; a.lda = s->Np_pad; a.B = s->d_B; a.ldb = s->fs_nodes;
+  a.C = s->d_feat; a.ldc = ldp;
+  a.M = s->Np_pad; a.N = TILE; a.K = s->fs_nodes; a.batch = 1; a.alpha = 1.0; a.beta = 0.0;
+  GP_TRY(launch_gemm(s->st, false, false, a));
+  GemmArgs m{};   // Gram matrix of every block's rows
+  m.A = s->d_feat; m.lda = ldp; m.strideA = TILE; m.B = m.A; m.ldb = ldp; m.strideB = TILE;
+  m.C = s->d_gparts; m.ldc = TILE; m.strideC = blk;
+  m.M = TILE; m.N = TILE; m.K = TILE; m.batch = nblk; m.alpha = 1.0; m.beta = 0.0;
+  GP_TRY(launch_gemm(s->st, true, false, m));
+  GP_TRY(launch_prefix_gram(s->st, s->d_gparts, nblk, s2, s->d_Jb));
+  GP_TRY(launch_potrf(s->st, s->d_Jb, TILE, nblk, s->d_jinv, s->d_info, s->d_fwork));
+  GemmArgs t{};   // T_b = s Phi_b R_b^-T
+  t.A = s->d_feat; t.lda = ldp; t.strideA = TILE; t.B = s->d_jinv; t.ldb = SUP; t.strideB = sI;
+  t.C = s->d_Tb; t.ldc = TILE; t.strideC = blk;
+  t.M = TILE; t.N = TILE; t.K = TILE; t.batch = nblk; t.alpha = sd; t.beta = 0.0;
+  GP_TRY(launch_gemm(s->st, false, true, t));
+  GP_TRY(launch_scaled_identity(s->st, s->d_Sbb, TILE, 0, nblk, blk, s2));
+  GemmArgs c{};   // s2 I + T_b T_b^T
+  c.A = s->d_Tb; c.lda = TILE; c.strideA = blk; c.B = s->d_Tb; c.ldb = TILE; c.strideB = blk;
+  c.C = s->d_Sbb; c.ldc = TILE; c.strideC = blk;
+  c.M = TILE; c.N = TILE; c.K = TILE; c.batch = nblk; c.alpha = 1.0; c.beta = 1.0;
+  GP_TRY(launch_gemm(s->st, false, true, c));
+  GP_TRY(launch_potrf(s->st, s->d_Sbb, TILE, nblk, s->d_linv, s->d_info, s->d_fwork));
+  GP_TRY(launch_tril(s->st, s->d_Sbb, nblk));
+  GemmArgs e{};   // L_bb^-1 T_b
+  e.A = s->d_linv; e.lda = SUP; e.strideA = sI; e.B = s->d_Tb; e.ldb = TILE; e.strideB = blk;
+  e.C = s->d_Et; e.ldc = TILE; e.strideC = blk;
+  e.M = TILE; e.N = TILE; e.K = TILE; e.batch = nblk; e.alpha = 1.0; e.beta = 0.0;
+  GP_TRY(launch_gemm(s->st, false, false, e));
+  GemmArgs w{};   // W_b^T = s (L_bb^-1 T_b) R_b^-1
+  w.A = s->d_Et; w.lda = TILE; w.strideA = blk; w.B = s->d_jinv; w.ldb = SUP; w.strideB = sI;
+  w.C = s->d_Wt; w.ldc = TILE; w.strideC = blk;
+  w.M = TILE; w.N = TILE; w.K = TILE; w.batch = nblk; w.alpha = sd; w.beta = 0.0;
+  GP_TRY(launch_gemm(s->st, false, false, w));
+  int info = 0;
+  GP_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, s->st));
+  GP_HIP(hipStreamSynchronize(s->st));
+  if (info) {
+    set_error("generator form of the prior factor: a block is not positive definite (pivot %d)", info);
+    return GPIRT_ERR_NOT_PD;
+  }
+  *done = 1;
+  return GPIRT_OK;
+}
+
 static int phase_factor(gpirt_sampler *s) {
+  s->gen_now = 0;
+  if (s->gen_prior) {
+    int done = 0;
+    GP_TRY(phase_factor_generator(s, &done));
+    if (done) { s->gen_now = 1; return GPIRT_OK; }
+  }
   for (;;) {
     GP_TRY(mark(s, PH_KBUILD));
     GP_TRY(launch_k_build(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
@@ -650,7 +762,27 @@ static int phase_f(gpirt_sampler *s) {
   // the XCD-aware tile order keeps HBM traffic down when there are many column tiles per row
   // panel; with fewer it is slower than plain longest-first (3.83 vs 3.59 ms at 2048 columns)
   g.k_trim = (s->Np_pad / TILE) * (s->ML / TILE) >= 2048 ? 3 : 1;
-  if (s->nu_splits > 1) {
+  if (s->gen_now) {
+    // nu_b = L_bb z_b + Phi_b sum_{b' < b} W_b' z_b'  (phase_factor_generator)
+    const int nblk = s->Np_pad / TILE;
+    const int64_t ldp = s->Np_pad + TILE, blk = (int64_t)TILE * TILE, vb = (int64_t)TILE * s->ML;
+    GemmArgs v{};   // V_b = W_b z_b
+    v.A = s->d_Wt; v.lda = TILE; v.strideA = blk; v.B = s->d_Z; v.ldb = s->Np_pad; v.strideB = TILE;
+    v.C = s->d_V; v.ldc = TILE; v.strideC = vb;
+    v.M = TILE; v.N = s->ML; v.K = TILE; v.batch = nblk; v.alpha = 1.0; v.beta = 0.0;
+    GP_TRY(launch_gemm(s->st, true, false, v));
+    GP_TRY(launch_prefix_blocks(s->st, s->d_V, vb, nblk));
+    GemmArgs l{};   // L_bb z_b
+    l.A = s->d_Sbb; l.lda = TILE; l.strideA = blk; l.B = s->d_Z; l.ldb = s->Np_pad; l.strideB = TILE;
+    l.C = s->d_nu; l.ldc = s->Np_pad; l.strideC = TILE;
+    l.M = TILE; l.N = s->ML; l.K = TILE; l.batch = nblk; l.alpha = 1.0; l.beta = 0.0;
+    GP_TRY(launch_gemm(s->st, false, false, l));
+    GemmArgs u{};   // + Phi_b U_b
+    u.A = s->d_feat; u.lda = ldp; u.strideA = TILE; u.B = s->d_V; u.ldb = TILE; u.strideB = vb;
+    u.C = s->d_nu; u.ldc = s->Np_pad; u.strideC = TILE;
+    u.M = TILE; u.N = s->ML; u.K = TILE; u.batch = nblk; u.alpha = 1.0; u.beta = 1.0;
+    GP_TRY(launch_gemm(s->st, false, false, u));
+  } else if (s->nu_splits > 1) {
     // the slabs of K run side by side and a small kernel adds them in fixed order
     const int kc = s->Np_pad / s->nu_splits;
     g.K = kc; g.k_shift = kc; g.batch = s->nu_splits;

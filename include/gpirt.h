@@ -72,9 +72,12 @@ enum {
                               respondents on; the flag forces it)                             */
   GPIRT_THETA_DIRECT = 32, /* respondent slice step: evaluate every cell in every round (default
                               below 1024 respondents; the flag forces it)                     */
-  GPIRT_FSTAR_SOLVE = 64   /* f* step: keep the interpolated cross-covariance but go through the
+  GPIRT_FSTAR_SOLVE = 64,  /* f* step: keep the interpolated cross-covariance but go through the
                               two triangular solves with the n x n factor instead of the low-rank
                               identity (see gpirt_sampler_sweep)                              */
+  GPIRT_GENERATOR_PRIOR = 128 /* keep the Cholesky factor of K(theta,theta) + s2 I in generator
+                              (block semiseparable) form instead of as an n x n matrix (see
+                              gpirt_sampler_sweep); one IRF group only, ignored otherwise      */
 };
 
 /* Sum-all-reduce hook used by the respondent step when items are sharded over
@@ -200,7 +203,18 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
  *                      while every input lies on the grid's range, else FSTAR_SOLVE's route;
  *   GPIRT_FSTAR_SOLVE  K(x, xs) = K(x, c) Lag interpolated in the grid argument only, two
  *                      triangular solves with the n x n factor for the 128 node columns;
- *   GPIRT_EXACT_FSTAR  K(x, xs) evaluated at every grid point, solves for all columns. */
+ *   GPIRT_EXACT_FSTAR  K(x, xs) evaluated at every grid point, solves for all columns.
+ *
+ * The prior draw nu = chol(K(x, x) + s2 I) z (sample_fs.m:2, demo.m:45) has two routes:
+ *   default                the n x n matrix is built and factorised (blocked, FP64 MFMA) and
+ *                          nu = L Z is one triangular product for all items;
+ *   GPIRT_GENERATOR_PRIOR  with the same node representation, K + s2 I = Phi Phi^T + s2 I has
+ *                          a factor whose blocks below the diagonal are Phi_i W_b: only the
+ *                          128 x 128 diagonal blocks and the generators W_b are computed
+ *                          (batched), nu costs O(n 128 m) instead of n^2 m, and the n x n matrix
+ *                          is never formed.  Same nu to about 1e-8 (the factor of a matrix that
+ *                          equals K + s2 I to 3e-15); a sweep whose inputs leave the grid's
+ *                          range takes the default route. */
 int gpirt_sampler_sweep(gpirt_sampler *s, int32_t sweeps);
 /* Copy the current state to host buffers (any may be NULL):
  * theta [n,H]; f [n,m_loc,H]; fstar [n_grid,m_loc,P]; beta [3,m_loc,P];

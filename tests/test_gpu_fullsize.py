@@ -96,7 +96,8 @@ def test_loglik_checksum_of_checksums_and_additivity(K):
     assert np.array_equal(lr_b[N // 2:], lr[N // 2:]) and not lr_b[:N // 2].any()
 
 
-@pytest.mark.parametrize("flags", [0, _abi.EXACT_FSTAR, _abi.THETA_DIRECT, _abi.FSTAR_SOLVE])
+@pytest.mark.parametrize("flags", [0, _abi.EXACT_FSTAR, _abi.THETA_DIRECT, _abi.FSTAR_SOLVE,
+                                   _abi.GENERATOR_PRIOR])
 def test_sweep_invariants(flags):
     """Two sweeps of the benchmark configuration.  Whatever was drawn: thresholds stay ordered
     with infinite ends, no slice update ran into the round cap, f was re-anchored on the grid

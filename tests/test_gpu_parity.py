@@ -168,6 +168,7 @@ def _pair(cfg, y, **kw):
                                                  ("2PL_C_5", 5, 1, _abi.EXACT_FSTAR),
                                                  ("Wiener_C_5", 5, 0, _abi.FSTAR_SOLVE),
                                                  ("2PL_C_5", 5, 1, _abi.FSTAR_SOLVE),
+                                                 ("2PL_C_5", 5, 1, _abi.GENERATOR_PRIOR),
                                                  ("2PL_C_2", 2, 0, _abi.THETA_TABLE),
                                                  ("Wiener_C_5", 5, 0, _abi.THETA_TABLE),
                                                  ("2PL_C_5", 5, 1, _abi.THETA_TABLE)])
@@ -199,6 +200,8 @@ def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const, flags):
 @pytest.mark.parametrize("n,m,sweeps,flags", [(1300, 9, 2, 0), (2100, 5, 1, 0),
                                               (2100, 5, 1, _abi.EXACT_FSTAR),
                                               (2100, 5, 1, _abi.FSTAR_SOLVE),
+                                              (2100, 5, 1, _abi.GENERATOR_PRIOR),
+                                              (1300, 9, 2, _abi.GENERATOR_PRIOR),
                                               (1300, 9, 2, _abi.THETA_DIRECT),
                                               (1100, 2100, 1, 0)])   # two item chunks per table row
 def test_sweep_matches_oracle_wide_units(n, m, sweeps, flags):
@@ -222,7 +225,7 @@ def test_sweep_matches_oracle_wide_units(n, m, sweeps, flags):
     g.close(); c.close()
 
 
-@pytest.mark.parametrize("flags", [0, _abi.EXACT_FSTAR, _abi.FSTAR_SOLVE])
+@pytest.mark.parametrize("flags", [0, _abi.EXACT_FSTAR, _abi.FSTAR_SOLVE, _abi.GENERATOR_PRIOR])
 def test_sweep_matches_oracle_many_items(flags):
     """More unit columns than grid points (ML >= G_pad = 1024): with the exact cross-covariance
     the f* phase then solves S^-1 K(x, xs) instead of S^-1 F; with FSTAR_SOLVE it solves for the
