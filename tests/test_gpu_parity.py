@@ -370,3 +370,40 @@ def test_checkpoint_restore_continues_the_chain_bit_for_bit():
     with pytest.raises(GpirtError):
         other.restore(blob)                                   # another seed: refused
     b.close(); other.close()
+
+
+@pytest.mark.parametrize("flags", [0, _abi.GENERATOR_PRIOR])
+def test_inputs_outside_the_node_range_take_the_dense_routes(flags):
+    """The low-rank f* step and the generator form of the prior factor interpolate the kernel on
+    the grid's range [-5, 5]; a sweep that starts with a theta outside it must notice and go
+    through the n x n factor instead.  Two respondents start at 5.6 and -6.2: the first sweep
+    runs the fallback, later ones (theta back inside) the default routes; parity bar unchanged."""
+    from gpirt_amd.synth import generate
+    d = generate(300, 7, 3, seed=12)
+    theta = d["theta"].copy()
+    theta[3, 0], theta[77, 0] = 5.6, -6.2
+    cfg = _abi.default_config(n=300, m=7, H=1, C=3, seed=4, flags=flags)
+    g, c = _pair(cfg, d["y"], theta_init=theta)
+    for sweep in range(3):
+        g.sweep(1); c.sweep(1)
+        sg, sc = g.state(), c.state()
+        for k in ("theta", "beta", "f", "fstar"):
+            assert np.abs(sg[k] - sc[k]).max() < 1e-5, (sweep, k)
+    assert g.diagnostics() == c.diagnostics()
+    g.close(); c.close()
+
+
+@pytest.mark.parametrize("flags", [0, _abi.GENERATOR_PRIOR])
+def test_short_length_scale_falls_back_to_the_dense_routes(flags):
+    """With irf_ls = 0.12 the kernel on [-5, 5] has far more than 128 significant eigenvalues:
+    the node representation is refused at set-up and every route is the dense one."""
+    from gpirt_amd.synth import generate
+    d = generate(200, 5, 2, seed=13)
+    cfg = _abi.default_config(n=200, m=5, H=1, C=2, seed=6, irf_ls=0.12, flags=flags)
+    g, c = _pair(cfg, d["y"], theta_init=d["theta"])
+    for sweep in range(2):
+        g.sweep(1); c.sweep(1)
+        sg, sc = g.state(), c.state()
+        for k in ("theta", "beta", "f", "fstar"):
+            assert np.abs(sg[k] - sc[k]).max() < 1e-5, (sweep, k)
+    g.close(); c.close()
