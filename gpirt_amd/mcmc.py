@@ -41,7 +41,7 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, THIN=1, CHAIN=1,
               vote_codes=None, thresholds=None, SEED=1, constant_IRF=0, KERNEL="RBF",
               beta_proposal_sds=None, *, return_f=True, return_fstar=True, theta_mode="ess",
               jitter=1e-6, max_ess_rounds=200, item_range=None, rank=0, world=1, allreduce=None,
-              progress=None, summary=False, summary_quadratic=False):
+              progress=None, summary=False, summary_quadratic=False, flags=0):
     """Run ``CHAIN`` independent chains; returns a list with one dict per chain holding
 
     ``theta [K, n, H]``, ``f [K, n, m, H]``, ``fstar [K, 1001, m, H]``, ``beta [K, 3, m, H]``,
@@ -52,6 +52,8 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, THIN=1, CHAIN=1,
     ignored (legacy arguments, gpirt_CIRI.R:135).  ``summary=True`` adds ``"summary"``: the
     posterior summaries accumulated on the device (``gpirt_amd.post`` turns them into the
     reference's evaluation metrics), so that ``return_f`` / ``return_fstar`` can be False.
+    ``flags`` is OR-ed into ``gpirt_config.flags`` (e.g. ``_abi.GENERATOR_PRIOR``: the prior
+    factor in generator form, see ``include/gpirt.h``).
     """
     del vote_codes, beta_proposal_sds
     y = responses_from_r(data)
@@ -66,7 +68,7 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, THIN=1, CHAIN=1,
     if KERNEL not in kernels:
         raise ValueError("KERNEL must be 'RBF' or 'Matern'")
     modes = {"ess": _abi.THETA_ESS, "grid": _abi.THETA_GRID}
-    flags = (_abi.RETURN_F if return_f else 0) | (_abi.RETURN_FSTAR if return_fstar else 0)
+    flags = int(flags) | (_abi.RETURN_F if return_f else 0) | (_abi.RETURN_FSTAR if return_fstar else 0)
     bpm = _prior_rows(beta_prior_means, 3, m, 0.0, "beta_prior_means")
     bps = _prior_rows(beta_prior_sds, 3, m, 0.0, "beta_prior_sds")
     thin = max(int(THIN), 1)
