@@ -103,7 +103,9 @@ def test_sweep_invariants(flags):
     with infinite ends, no slice update ran into the round cap, f was re-anchored on the grid
     curve at each respondent's new theta (main.m:69-73), and the variants of two steps lead to
     the same chain: low-rank identity / triangular solves with interpolated / exact
-    cross-covariance in the f* step (main.m:57-58), and in the respondent step table rows served per grid index / every cell evaluated in every round."""
+    cross-covariance in the f* step (main.m:57-58), table rows served per grid index / every
+    cell evaluated in every round in the respondent step, dense / generator form of the prior
+    factor."""
     from gpirt_amd.sampler import Sampler
     from gpirt_amd.synth import generate
     d = generate(N, M, C, seed=1)
