@@ -55,10 +55,12 @@ int launch_ess_param(hipStream_t st, const EssParamArgs &a);
 // ---- theta.hip -------------------------------------------------------------------------
 struct ThetaArgs {
   double *theta;            // [n,H] state
-  double *xc, *nu, *prop;   // [n,H] centred state, ellipse draw, centred proposal
-  double *hh, *phi, *pmin, *pmax;  // [n]
-  int32_t *done;            // [n]
-  double *buf;              // [n] log-likelihood (partial, then all-reduced)
+  double *xc, *nu;          // [n,H] centred state, ellipse draw
+  double *prop;             // [SPEC*n, H] centred proposals: entry k*n + i is respondent i's k-th of the round
+  double *hh, *pmin, *pmax; // [n] slice height, bracket before the round's proposals
+  double *phi;              // [SPEC*n] angles of the round's proposals
+  int32_t *done;            // [n] proposals of respondent i in flight this round (0: finished)
+  double *buf;              // [SPEC*n] log-likelihood per proposal (partial, then all-reduced)
   const double *Lt;         // [H,H] lower factor of the temporal kernel
   const double *tpm, *tps;  // [2,n]
   const double *Gt;         // [U_pad, G_pad] f* with the unit index contiguous
@@ -66,19 +68,26 @@ struct ThetaArgs {
   const int8_t *yT;         // [ML*H, n] responses, respondent-major
   double *tab;              // [U_pad, C, G] log cell probabilities on the grid (table variant) or null
   // bucketed evaluation of the table variant (H = 1): respondents grouped by grid index
-  int32_t *gidx, *order;    // [n] grid index of the evaluated theta (-1: not active), respondents by bucket
+  int32_t *gidx, *order;    // [SPEC*n] grid index of the evaluated theta (-1: none), entries by bucket
   int32_t *bstart;          // [G+1] bucket g holds order[bstart[g] .. bstart[g+1])
   int32_t *ghist;           // [G] respondents per grid index, counted by the prepare / decision kernels
-  double *part;             // [nchunks, n] partial sums per item chunk
+  double *part;             // [nchunks, SPEC*n] partial sums per item chunk
   int chunk, nchunks;       // items per chunk (multiple of 64), number of chunks
   int from_parts;           // the decision kernel sums `part` itself instead of reading `buf`
   int n, H, C, mloc, ML, U_pad, G, constant_irf, R;
   double grid_lo, grid_step;
   double os2;               // prior variance of the static step (theta_os^2, 1 when theta_os = 0)
   uint64_t seed; uint32_t sweep;
-  int32_t *remaining;       // [R+1] respondents still active after the decision of round r
+  int32_t *remaining;       // [R+4] respondents still active after the decision of round r; the last
+                            // entry: largest proposal number at which a respondent finished
   unsigned long long *counters;  // [1] capped
 };
+// Proposals per lock-step round.  After a rejection the next angle is a function of the
+// bracket and the generator alone, so a round draws each respondent's next THETA_SPEC
+// proposals as if all were rejected, evaluates them together and then takes the first one
+// that is accepted: same draws and decisions as one proposal per round, a quarter of the
+// rounds (launch gaps, host looks and, with sharded items, all-reduce latencies).
+constexpr int THETA_SPEC = 4;
 int launch_theta_prepare(hipStream_t st, const ThetaArgs &a);
 int launch_theta_eval(hipStream_t st, const ThetaArgs &a, int initial, bool wide);
 // tab[u + U_pad*(c + C*g)] = log P(y = c+1 | F*_u(x_g)); with a.tab set, launch_theta_eval sums
@@ -90,7 +99,9 @@ int launch_theta_table(hipStream_t st, const ThetaArgs &a);
 constexpr int THETA_BUCKET_MAX_G = 2048;
 int theta_bucket_chunk(int C);
 int launch_theta_eval_bucketed(hipStream_t st, const ThetaArgs &a, int initial);
-int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int round);
+// q0 = 0: set the slice height from the current state's log-likelihood and draw proposals
+// 1..SPEC; q0 > 0: the round evaluated proposals q0..q0+SPEC-1.  round = index into remaining.
+int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int q0, int round);
 // static (grid) respondent step, H = 1: one-hot coding of y (k = jl + ML*(y-1), ld = C*ML),
 // the per-sweep table of log cell probabilities T[G_pad, C*ML], and the inverse-CDF draw
 // from lp = T * onehot (+ prior)

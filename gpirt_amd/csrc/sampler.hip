@@ -491,12 +491,13 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   A_(s->d_bps, 3 * (size_t)mloc);
   A_(s->d_xc, (size_t)n * H);
   A_(s->d_tnu, (size_t)n * H);
-  A_(s->d_prop, (size_t)n * H);
-  A_(s->d_hh, n); A_(s->d_phi, n); A_(s->d_pmin, n); A_(s->d_pmax, n); A_(s->d_buf, n);
+  A_(s->d_prop, (size_t)THETA_SPEC * n * H);
+  A_(s->d_hh, n); A_(s->d_phi, (size_t)THETA_SPEC * n); A_(s->d_pmin, n); A_(s->d_pmax, n);
+  A_(s->d_buf, (size_t)THETA_SPEC * n);
   A_(s->d_Lt, (size_t)H * H);
   A_(s->d_tpm, 2 * (size_t)n); A_(s->d_tps, 2 * (size_t)n);
   A_(s->d_llu, U_pad);
-  A_(s->d_done, n); A_(s->d_info, 3); A_(s->d_remaining, (size_t)(s->cfg.max_ess_rounds + 2));
+  A_(s->d_done, n); A_(s->d_info, 3); A_(s->d_remaining, (size_t)(s->cfg.max_ess_rounds + 4));
   A_(s->d_counters, 6);
   // nu = L Z with few column tiles (a rank's share of the items, or a handful of items): the
   // longest row panel alone would set the time and most CUs would hold one workgroup or none,
@@ -524,8 +525,8 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     if (table && H == 1 && s->G <= THETA_BUCKET_MAX_G) {
       s->th_chunk = theta_bucket_chunk(C);
       s->th_nchunks = (mloc + s->th_chunk - 1) / s->th_chunk;
-      A_(s->d_part, (size_t)s->th_nchunks * n);
-      A_(s->d_gidx, n); A_(s->d_order, n); A_(s->d_bstart, (size_t)s->G + 1); A_(s->d_ghist, s->G);
+      A_(s->d_part, (size_t)s->th_nchunks * THETA_SPEC * n);
+      A_(s->d_gidx, (size_t)THETA_SPEC * n); A_(s->d_order, (size_t)THETA_SPEC * n); A_(s->d_bstart, (size_t)s->G + 1); A_(s->d_ghist, s->G);
     }
   }
 #undef A_
@@ -970,17 +971,18 @@ static int exchange(gpirt_sampler *s, double *buf = nullptr, int64_t count = 0) 
   return GPIRT_OK;
 }
 
-// Lock-step rounds.  The decision kernel of round r leaves the number of respondents still
-// active in remaining[r]; the host looks at that history only every few rounds (a look is a
-// stream drain plus a launch gap, dearer than a round in which nobody is active any more),
-// except with sharded items, where every round passes through the host for the exchange.
+// Lock-step rounds of THETA_SPEC proposals each.  The decision kernel of a round leaves the
+// number of respondents still active in remaining[round]; the host looks at that history only
+// after the second round and then after every round (a look is a stream drain plus a launch
+// gap), except with sharded items and a blocking hook, where every round passes through the
+// host for the exchange anyway.
 static int phase_theta(gpirt_sampler *s) {
   GP_TRY(mark(s, PH_THETA));
   ThetaArgs a = theta_args(s);
   const int R = a.R;
   // a hook that is not stream-ordered passes through the host every round anyway
   const bool sharded = s->cfg.world > 1 && !(s->cfg.flags & GPIRT_ALLREDUCE_ON_STREAM);
-  GP_HIP(hipMemsetAsync(s->d_remaining, 0, sizeof(int) * (size_t)(R + 2), s->st));
+  GP_HIP(hipMemsetAsync(s->d_remaining, 0, sizeof(int) * (size_t)(R + 4), s->st));
   if (a.part) GP_HIP(hipMemsetAsync(s->d_ghist, 0, sizeof(int32_t) * (size_t)s->G, s->st));
   GP_TRY(launch_theta_prepare(s->st, a));
   if (a.tab) GP_TRY(launch_theta_table(s->st, a));
@@ -998,31 +1000,33 @@ static int phase_theta(gpirt_sampler *s) {
   };
   GP_TRY(eval(1, many_items));
   GP_TRY(exchange(s));
-  s->theta_rounds++;
-  GP_TRY(launch_theta_decide(s->st, a, 0));
-  std::vector<int> hist((size_t)R + 2, 0);
+  GP_TRY(launch_theta_decide(s->st, a, 0, 0));
+  const int max_rounds = (R + THETA_SPEC - 1) / THETA_SPEC + 1;
+  std::vector<int> hist((size_t)R + 4, 0);
   int r = 1;
-  while (r <= R) {
-    // rounds r .. last run without a look at the counters
-    const int last = sharded ? r : min(R, r < 6 ? 6 : r + 2);
+  bool finished = false;
+  while (r <= max_rounds && !finished) {
+    const int last = sharded ? r : min(max_rounds, r < 2 ? 2 : r);
     const bool wide = many_items || active * 4 <= s->n;
     for (int q = r; q <= last; ++q) {
       GP_TRY(eval(0, wide));
-      GP_TRY(exchange(s));
-      GP_TRY(launch_theta_decide(s->st, a, q));
+      GP_TRY(exchange(s, s->d_buf, (int64_t)THETA_SPEC * s->n));
+      GP_TRY(launch_theta_decide(s->st, a, 1 + (q - 1) * THETA_SPEC, q));
     }
     GP_HIP(hipMemcpyAsync(hist.data() + r, s->d_remaining + r, sizeof(int) * (size_t)(last - r + 1),
                           hipMemcpyDeviceToHost, s->st));
+    GP_HIP(hipMemcpyAsync(hist.data() + R + 3, s->d_remaining + R + 3, sizeof(int), hipMemcpyDeviceToHost,
+                          s->st));
     GP_HIP(hipStreamSynchronize(s->st));
-    bool finished = false;
     for (int q = r; q <= last; ++q) {
-      s->theta_rounds++;
       active = hist[q];
       if (!active) { finished = true; break; }    // rounds after q (if any) found nobody active
     }
-    if (finished) break;
     r = last + 1;
   }
+  // what one proposal per lock-step round would have counted: the evaluation of the current
+  // state plus as many rounds as the slowest respondent needed proposals
+  s->theta_rounds += 1 + hist[(size_t)R + 3];
   return GPIRT_OK;
 }
 

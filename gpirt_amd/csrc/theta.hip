@@ -24,9 +24,9 @@ __device__ inline double prior_mean(const double *tpm, int i, int h) {
 
 // bucketed evaluation (H = 1): the kernel that fixes the theta to be evaluated next also
 // files the respondent under that theta's grid index
-__device__ inline void bucket_note(const ThetaArgs &a, int i, double th) {
+__device__ inline void bucket_note(const ThetaArgs &a, int v, double th) {
   const int g = grid_index(th, a.grid_lo, a.grid_step, a.G);
-  a.gidx[i] = g;
+  a.gidx[v] = g;
   atomicAdd(&a.ghist[g], 1);
 }
 
@@ -45,7 +45,7 @@ __global__ void theta_prepare_kernel(ThetaArgs a) {
     a.nu[i + (int64_t)n * h] = acc;
     a.xc[i + (int64_t)n * h] = a.theta[i + (int64_t)n * h] - prior_mean(a.tpm, i, h);
   }
-  a.done[i] = 0;
+  a.done[i] = 1;
   if (a.part) bucket_note(a, i, a.theta[i]);
 }
 
@@ -66,10 +66,13 @@ __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initia
   phi_table_to_lds(sphi);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = WPR == 1 ? blockIdx.x * 4 + w : blockIdx.x;
-  if (i >= a.n) return;
-  if (!initial && a.done[i]) {               // uniform over the workgroup when WPR = 4
-    if (lane == 0 && (WPR == 1 || w == 0)) a.buf[i] = 0.0;
+  const int v = WPR == 1 ? blockIdx.x * 4 + w : blockIdx.x;      // entry k*n + i
+  const int count = initial ? a.n : THETA_SPEC * a.n;
+  if (v >= count) return;
+  const int i = v % a.n;
+  const int64_t V = (int64_t)THETA_SPEC * a.n;
+  if (!initial && v / a.n >= a.done[i]) {    // uniform over the workgroup when WPR = 4
+    if (lane == 0 && (WPR == 1 || w == 0)) a.buf[v] = 0.0;
     return;
   }
   const int H = a.H, n = a.n, mloc = a.mloc, ML = a.ML, U_pad = a.U_pad;
@@ -78,8 +81,7 @@ __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initia
   LogProduct prod;
   prod.reset();
   for (int h = 0; h < H; ++h) {
-    double th = initial ? a.theta[i + (int64_t)n * h]
-                        : a.prop[i + (int64_t)n * h] + prior_mean(a.tpm, i, h);
+    double th = initial ? a.theta[i + (int64_t)n * h] : a.prop[v + V * h] + prior_mean(a.tpm, i, h);
     const int g = grid_index(th, a.grid_lo, a.grid_step, a.G);
     const double xg = a.grid_lo + a.grid_step * g;
     const int p = a.constant_irf ? 0 : h;
@@ -108,11 +110,11 @@ __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initia
   }
   const double acc = wave_sum(prod.log_value());
   if (WPR == 1) {
-    if (lane == 0) a.buf[i] = acc;
+    if (lane == 0) a.buf[v] = acc;
   } else {
     if (lane == 0) red[w] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) a.buf[i] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) a.buf[v] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
@@ -150,10 +152,13 @@ template <int WPR>
 __global__ __launch_bounds__(256) void theta_eval_table_kernel(ThetaArgs a, int initial) {
   __shared__ double red[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = WPR == 1 ? blockIdx.x * 4 + w : blockIdx.x;
-  if (i >= a.n) return;
-  if (!initial && a.done[i]) {               // uniform over the workgroup when WPR = 4
-    if (lane == 0 && (WPR == 1 || w == 0)) a.buf[i] = 0.0;
+  const int v = WPR == 1 ? blockIdx.x * 4 + w : blockIdx.x;      // entry k*n + i
+  const int count = initial ? a.n : THETA_SPEC * a.n;
+  if (v >= count) return;
+  const int i = v % a.n;
+  const int64_t V = (int64_t)THETA_SPEC * a.n;
+  if (!initial && v / a.n >= a.done[i]) {    // uniform over the workgroup when WPR = 4
+    if (lane == 0 && (WPR == 1 || w == 0)) a.buf[v] = 0.0;
     return;
   }
   const int H = a.H, n = a.n, mloc = a.mloc, ML = a.ML;
@@ -161,8 +166,7 @@ __global__ __launch_bounds__(256) void theta_eval_table_kernel(ThetaArgs a, int 
   const int jfirst = WPR == 1 ? lane : lane + 64 * w, jstep = 64 * WPR;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   for (int h = 0; h < H; ++h) {
-    double th = initial ? a.theta[i + (int64_t)n * h]
-                        : a.prop[i + (int64_t)n * h] + prior_mean(a.tpm, i, h);
+    double th = initial ? a.theta[i + (int64_t)n * h] : a.prop[v + V * h] + prior_mean(a.tpm, i, h);
     const int g = grid_index(th, a.grid_lo, a.grid_step, a.G);
     const int p = a.constant_irf ? 0 : h;
     const double *row = a.tab + U_pad * a.C * g + (int64_t)ML * p;
@@ -185,11 +189,11 @@ __global__ __launch_bounds__(256) void theta_eval_table_kernel(ThetaArgs a, int 
   }
   const double acc = wave_sum((s0 + s1) + (s2 + s3));
   if (WPR == 1) {
-    if (lane == 0) a.buf[i] = acc;
+    if (lane == 0) a.buf[v] = acc;
   } else {
     if (lane == 0) red[w] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) a.buf[i] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) a.buf[v] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
@@ -199,10 +203,10 @@ __global__ __launch_bounds__(256) void theta_eval_table_kernel(ThetaArgs a, int 
 // from wherever the cache hierarchy still holds it: a round over all respondents moves
 // ~1.6 GB.  Grouped by grid index, a row chunk is read once, kept in LDS, and serves every
 // respondent of its bucket.
-__global__ __launch_bounds__(1024) void theta_bucket_kernel(ThetaArgs a) {
+__global__ __launch_bounds__(1024) void theta_bucket_kernel(ThetaArgs a, int count) {
   __shared__ int hist[THETA_BUCKET_MAX_G];
   __shared__ int lane_tot[64];
-  const int tid = threadIdx.x, n = a.n, G = a.G;
+  const int tid = threadIdx.x, n = count, G = a.G;
   for (int g = tid; g < THETA_BUCKET_MAX_G; g += 1024) {
     hist[g] = g < G ? a.ghist[g] : 0;
     if (g < G) a.ghist[g] = 0;                            // ready for the next round's counts
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(1024) void theta_bucket_kernel(ThetaArgs a) {
   for (int g = tid; g < G; g += 1024) a.bstart[g] = hist[g];
   if (tid == 0) a.bstart[G] = lane_tot[63];
   __syncthreads();
-  constexpr int B = 10;    // respondents per thread and trip: their loads are issued together
+  constexpr int B = 10;    // entries per thread and trip: their loads are issued together
   for (int base = tid; base < n; base += 1024 * B) {
     int gs[B];
 #pragma unroll
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256) void theta_eval_bucket_kernel(ThetaArgs a) {
   }
   int yv[PER], yn[PER];
   auto load_y = [&](int i, int *dst) {
-    const int8_t *yr = a.yT + (int64_t)a.ML * i + j0;
+    const int8_t *yr = a.yT + (int64_t)a.ML * (i % a.n) + j0;     // i: entry k*n + respondent
 #pragma unroll
     for (int t = 0; t < PER; ++t) dst[t] = yr[min(lane + 64 * t, cnt - 1)];
   };
@@ -296,20 +300,21 @@ __global__ __launch_bounds__(256) void theta_eval_bucket_kernel(ThetaArgs a) {
       s1 += (yv[t + 1] > 0 && lane + 64 * (t + 1) < cnt) ? v1 : 0.0;
     }
     const double acc = wave_sum(s0 + s1);
-    if (lane == 0) a.part[(int64_t)ch * a.n + i0] = acc;
+    if (lane == 0) a.part[(int64_t)ch * THETA_SPEC * a.n + i0] = acc;
 #pragma unroll
     for (int t = 0; t < PER; ++t) yv[t] = yn[t];
     i0 = i1; i1 = i2;
   }
 }
 
-__global__ void theta_sum_chunks_kernel(ThetaArgs a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
+__global__ void theta_sum_chunks_kernel(ThetaArgs a, int count) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= count) return;
+  const int64_t V = (int64_t)THETA_SPEC * a.n;
   double s = 0.0;
-  if (a.gidx[i] >= 0)
-    for (int ch = 0; ch < a.nchunks; ++ch) s += a.part[(int64_t)ch * a.n + i];
-  a.buf[i] = s;
+  if (a.gidx[v] >= 0)
+    for (int ch = 0; ch < a.nchunks; ++ch) s += a.part[V * ch + v];
+  a.buf[v] = s;
 }
 
 // items per chunk: C rows of `chunk` doubles in at most 48 KB of LDS
@@ -317,78 +322,117 @@ int theta_bucket_chunk(int C) { return min(BUCKET_CHUNK_MAX, max(64, (6144 / C) 
 
 int launch_theta_eval_bucketed(hipStream_t st, const ThetaArgs &a, int initial) {
   if (a.H != 1 || a.G > THETA_BUCKET_MAX_G || !a.tab || !a.part) return GPIRT_ERR_BAD_ARG;
-  hipLaunchKernelGGL(theta_bucket_kernel, dim3(1), dim3(1024), 0, st, a);
+  const int count = initial ? a.n : THETA_SPEC * a.n;
+  hipLaunchKernelGGL(theta_bucket_kernel, dim3(1), dim3(1024), 0, st, a, count);
   GP_HIP(hipGetLastError());
   hipLaunchKernelGGL(theta_eval_bucket_kernel, dim3(a.G, a.nchunks), dim3(256),
                      sizeof(double) * (size_t)a.C * a.chunk, st, a);
   GP_HIP(hipGetLastError());
   if (!a.from_parts) {     // someone other than the decision kernel needs the sums (the exchange)
-    hipLaunchKernelGGL(theta_sum_chunks_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(theta_sum_chunks_kernel, dim3((count + 255) / 256), dim3(256), 0, st, a, count);
     GP_HIP(hipGetLastError());
   }
   return GPIRT_OK;
 }
 
 int launch_theta_eval(hipStream_t st, const ThetaArgs &a, int initial, bool wide) {
+  const int count = initial ? a.n : THETA_SPEC * a.n;
+  const dim3 grid(wide ? count : (count + 3) / 4);
   if (a.tab) {
-    if (wide) hipLaunchKernelGGL(theta_eval_table_kernel<4>, dim3(a.n), dim3(256), 0, st, a, initial);
-    else hipLaunchKernelGGL(theta_eval_table_kernel<1>, dim3((a.n + 3) / 4), dim3(256), 0, st, a, initial);
-    GP_HIP(hipGetLastError());
-    return GPIRT_OK;
+    if (wide) hipLaunchKernelGGL(theta_eval_table_kernel<4>, grid, dim3(256), 0, st, a, initial);
+    else hipLaunchKernelGGL(theta_eval_table_kernel<1>, grid, dim3(256), 0, st, a, initial);
+  } else {
+    if (wide) hipLaunchKernelGGL(theta_eval_kernel<4>, grid, dim3(256), 0, st, a, initial);
+    else hipLaunchKernelGGL(theta_eval_kernel<1>, grid, dim3(256), 0, st, a, initial);
   }
-  if (wide) hipLaunchKernelGGL(theta_eval_kernel<4>, dim3(a.n), dim3(256), 0, st, a, initial);
-  else hipLaunchKernelGGL(theta_eval_kernel<1>, dim3((a.n + 3) / 4), dim3(256), 0, st, a, initial);
   GP_HIP(hipGetLastError());
   return GPIRT_OK;
 }
 
-// accept / shrink (elliptical_slice.m:66-100); round 0 sets the slice height and the first
-// proposal from the log-likelihood of the current state
-__global__ void theta_decide_kernel(ThetaArgs a, int round) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// accept / shrink (elliptical_slice.m:66-100).  q0 = 0 sets the slice height from the
+// log-likelihood of the current state; q0 > 0 goes through the round's proposals
+// q0, q0+1, ... in order and stops at the first accepted one.  A respondent that is still
+// active then gets its next THETA_SPEC proposals, each drawn from the bracket that the
+// rejection of the one before would leave (:92-100).
+__global__ void theta_decide_kernel(ThetaArgs a, int q0, int round) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   const int H = a.H, n = a.n;
-  double ll;
-  if (a.from_parts) {        // bucketed evaluation: the chunk partials, summed in fixed order
-    ll = 0.0;
-    for (int ch = 0; ch < a.nchunks; ++ch) ll += a.part[(int64_t)ch * n + i];
+  const int64_t V = (int64_t)THETA_SPEC * n;
+  auto value = [&](int k) -> double {
+    const int64_t v = (int64_t)k * n + i;
+    if (!a.from_parts) return a.buf[v];
+    double ll = 0.0;         // bucketed evaluation: the chunk partials, summed in fixed order
+    for (int ch = 0; ch < a.nchunks; ++ch) ll += a.part[V * ch + v];
+    return ll;
+  };
+  auto finish = [&](int q, bool capped) {
+    a.done[i] = 0;
+    atomicMax(&a.remaining[a.R + 3], q);
+    if (capped) atomicAdd(&a.counters[1], 1ull);
+    if (a.part)
+      for (int k = 0; k < THETA_SPEC; ++k) a.gidx[(int64_t)k * n + i] = -1;
+  };
+  double lo, hi, first_phi = 0.0;
+  int q;                                       // number of the next proposal
+  if (q0 == 0) {
+    a.hh[i] = log(rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, 0)) + value(0);
+    first_phi = rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, 1) * kTwoPi;
+    lo = first_phi - kTwoPi;
+    hi = first_phi;
+    q = 1;
   } else {
-    ll = a.buf[i];
-  }
-  double phi;
-  if (round == 0) {
-    a.hh[i] = log(rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, 0)) + ll;
-    phi = rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, 1) * kTwoPi;
-    a.pmin[i] = phi - kTwoPi;
-    a.pmax[i] = phi;
-  } else {
-    if (a.done[i]) return;
-    if (ll > a.hh[i]) {
-      for (int h = 0; h < H; ++h)
-        a.theta[i + (int64_t)n * h] = a.prop[i + (int64_t)n * h] + prior_mean(a.tpm, i, h);
-      a.done[i] = 1;
-      if (a.part) a.gidx[i] = -1;
-      return;
+    const int nv = a.done[i];
+    if (nv == 0) return;
+    const double hh = a.hh[i];
+    lo = a.pmin[i];
+    hi = a.pmax[i];
+    for (int k = 0; k < nv; ++k) {
+      const int qk = q0 + k;
+      if (value(k) > hh) {
+        for (int h = 0; h < H; ++h)
+          a.theta[i + (int64_t)n * h] = a.prop[(int64_t)k * n + i + V * h] + prior_mean(a.tpm, i, h);
+        finish(qk, false);
+        return;
+      }
+      const double phi = a.phi[(int64_t)k * n + i];
+      if (phi > 0.0) hi = phi;
+      else if (phi < 0.0) lo = phi;
+      else { finish(qk, true); return; }
+      if (qk >= a.R) { finish(qk, true); return; }
     }
-    phi = a.phi[i];
-    if (phi > 0.0) a.pmax[i] = phi;
-    else if (phi < 0.0) a.pmin[i] = phi;
-    else { a.done[i] = 1; if (a.part) a.gidx[i] = -1; atomicAdd(&a.counters[1], 1ull); return; }
-    if (round >= a.R) { a.done[i] = 1; if (a.part) a.gidx[i] = -1; atomicAdd(&a.counters[1], 1ull); return; }
-    double lo = a.pmin[i], hi = a.pmax[i];
-    phi = rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, (uint32_t)(1 + round)) * (hi - lo) + lo;
+    q = q0 + nv;             // all rejected: nv = THETA_SPEC here (a shorter chain ends above)
   }
-  a.phi[i] = phi;
-  double s, c;
-  sincos(phi, &s, &c);
-  for (int h = 0; h < H; ++h)
-    a.prop[i + (int64_t)n * h] = a.xc[i + (int64_t)n * h] * c + a.nu[i + (int64_t)n * h] * s;
-  if (a.part) bucket_note(a, i, a.prop[i] + prior_mean(a.tpm, i, 0));
+  a.pmin[i] = lo;
+  a.pmax[i] = hi;
+  int cnt = 0;
+  double phi = 0.0;
+  for (int k = 0; k < THETA_SPEC; ++k) {
+    const int qk = q + k;
+    if (k > 0) {             // as if proposal qk - 1 had been rejected
+      if (phi > 0.0) hi = phi;
+      else if (phi < 0.0) lo = phi;
+      else break;
+      if (qk - 1 >= a.R) break;
+    }
+    phi = qk == 1 ? first_phi
+                  : rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, (uint32_t)qk) * (hi - lo) + lo;
+    const int64_t v = (int64_t)k * n + i;
+    a.phi[v] = phi;
+    double s, c;
+    sincos(phi, &s, &c);
+    for (int h = 0; h < H; ++h) a.prop[v + V * h] = a.xc[i + (int64_t)n * h] * c + a.nu[i + (int64_t)n * h] * s;
+    if (a.part) bucket_note(a, (int)v, a.prop[v] + prior_mean(a.tpm, i, 0));
+    ++cnt;
+  }
+  if (a.part)
+    for (int k = cnt; k < THETA_SPEC; ++k) a.gidx[(int64_t)k * n + i] = -1;
+  a.done[i] = cnt;
   atomicAdd(&a.remaining[round], 1);
 }
 
-int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int round) {
-  hipLaunchKernelGGL(theta_decide_kernel, dim3((a.n + 127) / 128), dim3(128), 0, st, a, round);
+int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int q0, int round) {
+  hipLaunchKernelGGL(theta_decide_kernel, dim3((a.n + 127) / 128), dim3(128), 0, st, a, q0, round);
   GP_HIP(hipGetLastError());
   return GPIRT_OK;
 }
