@@ -42,6 +42,27 @@ def test_struct_layout_matches_header_defaults():
     assert lib.gpirt_version().startswith(b"gpirt-hip")
 
 
+def test_flag_values_match_the_header():
+    text = open(os.path.join(ROOT, "include", "gpirt.h")).read()
+    flags = dict(re.findall(r"\bGPIRT_([A-Z_]+)\s*=\s*(\d+)\s*[,/\n]", text))
+    for name in ("RETURN_F", "RETURN_FSTAR", "ALLREDUCE_ON_STREAM", "EXACT_FSTAR", "THETA_TABLE",
+                 "THETA_DIRECT", "FSTAR_SOLVE", "GENERATOR_PRIOR"):
+        assert int(flags[name]) == getattr(_abi, name), name
+    values = [getattr(_abi, n) for n in ("RETURN_F", "RETURN_FSTAR", "ALLREDUCE_ON_STREAM", "EXACT_FSTAR",
+                                         "THETA_TABLE", "THETA_DIRECT", "FSTAR_SOLVE", "GENERATOR_PRIOR")]
+    assert len(set(values)) == len(values) and all(v & (v - 1) == 0 for v in values)   # distinct bits
+
+
+def test_generator_prior_refuses_the_routes_that_need_the_dense_factor():
+    cfg = _abi.default_config(n=10, m=3, H=1, C=2, flags=_abi.GENERATOR_PRIOR | _abi.FSTAR_SOLVE)
+    h = C.c_void_p()
+    y = np.ones((10, 3, 1), dtype=np.int8)
+    rc = _lib.lib().gpirt_sampler_create(C.byref(cfg), y.ctypes.data_as(C.POINTER(C.c_int8)), None, None,
+                                         None, None, None, None, C.byref(h))
+    assert rc == _abi.GPIRT_ERR_BAD_ARG
+    assert b"GENERATOR_PRIOR" in _lib.lib().gpirt_last_error()
+
+
 @pytest.mark.skipif(_lib.lib().gpirt_device_count() > 0, reason="a GPU is visible")
 def test_no_cpu_fallback_without_device():
     from gpirt_amd import kernels
