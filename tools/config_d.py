@@ -12,7 +12,8 @@ from gpirt_amd.sampler import Sampler
 d = np.load(os.path.join(ROOT, "tests", "golden", "taps_cube.npz"))
 y = d["data"]
 n, m, H = y.shape
-cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=1, theta_os=1.0, theta_ls=12.0, constant_irf=1)
+cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=1, theta_os=1.0, theta_ls=12.0, constant_irf=1,
+                          flags=int(sys.argv[2]) if len(sys.argv) > 2 else 0)   # argv: sweeps [flags]
 bps = np.full((3, m), 3.0); bps[0] = 0.0; bps[2] = 0.0
 tps = np.ones((2, n)); tps[1] = 0.0
 s = Sampler(cfg, y, theta_init=standardised_row_scores(y), beta_prior_sds=bps, theta_prior_sds=tps)
