@@ -407,3 +407,19 @@ def test_short_length_scale_falls_back_to_the_dense_routes(flags):
         for k in ("theta", "beta", "f", "fstar"):
             assert np.abs(sg[k] - sc[k]).max() < 1e-5, (sweep, k)
     g.close(); c.close()
+
+
+def test_gpirtmcmc_passes_flags_through():
+    """The mirror's `flags` reach gpirt_config: the generator form of the prior factor through
+    gpirt_run gives the chain of the dense route (constant IRF: one group of 400 stacked inputs)."""
+    from gpirt_amd.mcmc import gpirtMCMC
+    d = load_fixture("2PL_C_5")
+    y, theta = d["y"][:, :, :4], d["theta"][:, :4]
+    kw = dict(THIN=2, theta_os=1.0, theta_ls=2.0, theta_init=theta, SEED=2, constant_IRF=1)
+    a = gpirtMCMC(y, 8, 4, **kw)[0]
+    b = gpirtMCMC(y, 8, 4, flags=_abi.GENERATOR_PRIOR, **kw)[0]
+    for k in ("theta", "f", "fstar", "beta"):
+        assert np.abs(np.asarray(a[k]) - np.asarray(b[k])).max() < 1e-5, k
+    da, db = dict(a["diagnostics"]), dict(b["diagnostics"])
+    da.pop("seconds"); db.pop("seconds")
+    assert da == db
