@@ -22,6 +22,7 @@ THETA_TABLE = 16
 THETA_DIRECT = 32
 FSTAR_SOLVE = 64
 GENERATOR_PRIOR = 128
+NO_NU_OVERLAP = 256
 
 # stream tags of the counter-based generator (same values in both backends)
 TAG_F_Z, TAG_F_U, TAG_P_Z, TAG_P_U, TAG_T_Z, TAG_T_U, TAG_INIT = 1, 2, 3, 4, 5, 6, 7
@@ -90,7 +91,7 @@ class GpirtOutputs(C.Structure):
         ("ess_theta_rounds", C.c_int64),
         ("ess_capped", C.c_int64),
         ("jitter_retries", C.c_int32),
-        ("reserved", C.c_int32),
+        ("nu_rows_beside_factor", C.c_int32),
         ("seconds_total", C.c_double),
     ]
 

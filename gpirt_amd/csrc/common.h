@@ -132,9 +132,13 @@ struct GemmArgs {
   int lower_only;    // compute only tiles with row-block >= col-block (C square)
   int k_trim;        // 1: A is lower-triangular => K range of row-block bi is [0,(bi+1)*TILE)
                      // 2: A^T is used with A lower-triangular => K range is [bi*TILE, K)
-                     // 3: as 1, instantiated under its own kernel name (the nu = L*Z launch)
+                     // 3: as 1, instantiated under its own kernel name (the nu = L*Z launch),
+                     //    tiles in the XCD-aware order; 4: as 1 under a third kernel name (the
+                     //    rows of nu left over after the factorisation)
   int k_shift;       // k_trim 1 or 3 with the batch index used to split K: slab z holds the K
                      // columns from z*k_shift on, so its trimmed range ends z*k_shift earlier
+  int k_base;        // k_trim 1 or 3 on a row range of the triangular matrix that starts at row
+                     // k_base (A and C point at that row): the trimmed range ends k_base later
 };
 // C = alpha * op(A) * op(B) + beta * C.
 //   AT = false: A(i,k) at A[i + lda*k];  AT = true: A(i,k) at A[k + lda*i]
@@ -163,8 +167,12 @@ inline int64_t potrf_work_elems(int n_pad, int batch) {
 // In-place lower Cholesky of `batch` padded matrices + the inverted diagonal super-blocks
 // (inv must be zero-initialised once); *d_info (device int) is set non-zero when a pivot is
 // not positive.
+// `hook` (optional) is called on the host right after the launches that finish block columns
+// [o, oe) and the trailing update behind them have been enqueued: from then on (in stream order)
+// rows [o*TILE, oe*TILE) of L are final and the chain of small kernels of the next block columns begins.
+struct PotrfHook { int (*fn)(void *ctx, int o, int oe); void *ctx; };
 int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, int *d_info,
-                 double *work);
+                 double *work, const PotrfHook *hook = nullptr);
 // B <- S^-1 B (two blocked triangular solves) for `batch` systems sharing the layout;
 // xtmp holds 4 * SUP * nrhs_pad doubles per system (split-K slabs of the diagonal steps).
 int launch_potrs(hipStream_t st, const double *L, const double *inv, int n_pad, int batch,

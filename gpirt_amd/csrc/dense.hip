@@ -73,7 +73,9 @@ __device__ __forceinline__ double slab_at(const double *s, int k, int idx) {
 
 // MODE: 0 plain, 1 lower tiles only (C square), 2 A lower-triangular (K range of row-block
 // bi is [0,(bi+1)*TILE)), 3 A^T with A lower-triangular (K range [bi*TILE, K)), 4 = 2 under
-// a name of its own for the once-per-sweep nu = L*Z launch (so that a profile lists it apart).
+// a name of its own for the once-per-sweep nu = L*Z launch (so that a profile lists it apart),
+// tiles in an XCD-aware order; 5 = 2 under a third name: the launch that computes the rows of nu
+// left over when the first rows have been computed beside the factorisation.
 template <bool AT, bool BT, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, int nbn) {
   constexpr bool AK = AT, BKC = !BT;   // is the K index the contiguous one?
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
     bi = nbm - 1 - (sbi * 8 + (inner >> 2));
     bj = sbj * 4 + (inner & 3);
     if (bi < 0 || bj >= nbn) return;
-  } else if (MODE == 2) {   // longest K first
+  } else if (MODE == 2 || MODE == 5) {   // longest K first
     bi = nbm - 1 - t / nbn; bj = t % nbn;
   } else {
     bi = t / nbn; bj = t % nbn;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
   double *C = g.C + g.strideC * z;   // may alias A or B (in-place panel and solve steps)
   const int i0 = bi * TILE, j0 = bj * TILE;
   int kbeg = 0, kend = g.K;
-  if (MODE == 2 || MODE == 4) kend = min(g.K, (bi + 1) * TILE - z * g.k_shift);   // may be <= 0: a zero tile
+  if (MODE == 2 || MODE == 4 || MODE == 5) kend = min(g.K, (bi + 1) * TILE + g.k_base - z * g.k_shift);   // may be <= 0: a zero tile
   if (MODE == 3) kbeg = bi * TILE;
   const int64_t lda = g.lda, ldb = g.ldb;
 
@@ -322,6 +324,7 @@ static int launch_gemm_mode(hipStream_t st, const GemmArgs &a, int mode, dim3 gr
     case 1: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, 1>), grid, block, 0, st, a, nbm, nbn); break;
     case 2: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, 2>), grid, block, 0, st, a, nbm, nbn); break;
     case 4: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, 4>), grid, block, 0, st, a, nbm, nbn); break;
+    case 5: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, 5>), grid, block, 0, st, a, nbm, nbn); break;
     default: hipLaunchKernelGGL((gemm_f64_kernel<AT, BT, 3>), grid, block, 0, st, a, nbm, nbn); break;
   }
   GP_HIP(hipGetLastError());
@@ -335,7 +338,7 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
     return GPIRT_ERR_BAD_ARG;
   }
   int nbm = a.M / TILE, nbn = a.N / TILE;
-  int mode = a.lower_only ? 1 : (a.k_trim == 1 ? 2 : (a.k_trim == 2 ? 3 : (a.k_trim == 3 ? 4 : 0)));
+  int mode = a.lower_only ? 1 : (a.k_trim == 1 ? 2 : (a.k_trim == 2 ? 3 : (a.k_trim == 3 ? 4 : (a.k_trim == 4 ? 5 : 0))));
   int64_t tiles = a.lower_only ? (int64_t)nbm * (nbm + 1) / 2 : (int64_t)nbm * nbn;
   if (mode == 4) {   // whole 8x4 super-tiles, a multiple of 8 of them (one share per XCD)
     int64_t nsup = (int64_t)((nbm + 7) / 8) * ((nbn + 3) / 4);
@@ -353,7 +356,7 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
   }
   dim3 grid((unsigned)tiles, (unsigned)a.batch);
   // only the combinations the sweep uses are instantiated
-  if (!AT && !BT && (mode == 0 || mode == 2 || mode == 4)) return launch_gemm_mode<false, false>(st, a, mode, grid, nbm, nbn);
+  if (!AT && !BT && (mode == 0 || mode == 2 || mode == 4 || mode == 5)) return launch_gemm_mode<false, false>(st, a, mode, grid, nbm, nbn);
   if (!AT && BT && (mode == 0 || mode == 1)) return launch_gemm_mode<false, true>(st, a, mode, grid, nbm, nbn);
   if (AT && !BT && (mode == 0 || mode == 3)) return launch_gemm_mode<true, false>(st, a, mode, grid, nbm, nbn);
   set_error("launch_gemm: combination AT=%d BT=%d mode=%d is not built", (int)AT, (int)BT, mode);
@@ -592,7 +595,7 @@ static int build_super_inverses(hipStream_t st, const double *L, int n_pad, doub
 // faster: the one-workgroup diagonal kernel needs a whole CU's LDS and only starts when the
 // update, which fills every CU, drains.
 int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, int *d_info,
-                 double *work) {
+                 double *work, const PotrfHook *hook) {
   const int nb = n_pad / TILE;
   const int64_t sS = (int64_t)n_pad * n_pad, sI = inv_group_elems(n_pad);
   auto panel_solve = [&](int k) -> int {   // L_ik = A_ik * inv(L_kk)^T, i > k
@@ -631,6 +634,7 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
       u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
       GP_TRY(launch_gemm(st, false, true, u));
     }
+    if (hook) GP_TRY(hook->fn(hook->ctx, o, oe));
   }
   if (nb > 1)
     for (int z = 0; z < batch; ++z)

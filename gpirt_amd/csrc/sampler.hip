@@ -133,6 +133,23 @@ struct gpirt_sampler {
   std::vector<hipEvent_t> ev;
   size_t ev_used;
   std::vector<int> ev_phase;
+  // nu = L Z beside the factorisation: the rows of the first nu_overlap super-panels (SUP rows
+  // each) are computed on a second stream, in chunks of nu_chunk tile rows, once those rows of L
+  // are final and the trailing update that followed them has drained -- beside the next
+  // super-panels' chain of small kernels, which leaves most CUs idle.  A chunk is sized to put
+  // one workgroup on most CUs and leave some CUs empty: the diagonal-block kernel needs a whole
+  // CU's LDS.  The result is the same bit for bit (same per-tile arithmetic), so the sampler
+  // times the factor + nu span with and without it in its first sweeps and keeps the faster.
+  hipStream_t st2;
+  std::vector<hipEvent_t> ev_panel;
+  hipEvent_t ev_join, ev_span[2][2];   // [sweep parity][begin, end] of the factor + nu span
+  int nu_overlap, nu_chunk, nu_rows_done, z_filled;
+  int ov_now;          // this sweep computes rows beside the factorisation
+  int ov_choice;       // -1: still measuring; 0 / 1: decided (or forced)
+  int dense_sweeps;    // sweeps that took the dense route so far
+  int span_open;       // parity + 1 of the span this sweep has begun (0: none)
+  int span_kind[2];    // what the span of that parity measured: -1 nothing, 0 without, 1 with
+  float ov_ms[2];      // measured span without / with
 };
 
 static void sampler_free(gpirt_sampler *s) {
@@ -148,6 +165,10 @@ static void sampler_free(gpirt_sampler *s) {
                   s->d_Jb, s->d_jinv, s->d_Tb, s->d_Sbb, s->d_linv, s->d_Et, s->d_Wt, s->d_V};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : s->ev_panel) (void)hipEventDestroy(e);
+  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+  for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) if (s->ev_span[a][b]) (void)hipEventDestroy(s->ev_span[a][b]);
+  if (s->st2) (void)hipStreamDestroy(s->st2);
   if (s->st) (void)hipStreamDestroy(s->st);
   delete s;
 }
@@ -512,6 +533,35 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     s->nu_splits = want;
     if (want > 1) A_(s->d_nuparts, (size_t)want * Np_pad * ML);
   }
+  s->nu_overlap = 0;
+  s->ov_choice = 0;
+  if (s->nu_splits == 1 && Np_pad >= 8 * SUP && !(cfg->flags & GPIRT_NO_NU_OVERLAP)) {
+    // GPIRT_NU_OVERLAP=k forces k super-panels (0: none) and GPIRT_NU_CHUNK=t the chunk size;
+    // by default about 0.6 of the rows, cut so that the rows left for the launch after the
+    // factorisation make just under 1024 tiles (two full rounds of workgroups)
+    const int nsup = inv_nsup(Np_pad), ncol = ML / TILE;
+    const char *e = getenv("GPIRT_NU_OVERLAP"), *c = getenv("GPIRT_NU_CHUNK");
+    int k = (s->nb - 1024 / ncol + 3) / 4;
+    k = max((nsup + 1) / 2, min(k, nsup * 3 / 4));
+    s->nu_overlap = e ? min(atoi(e), nsup) : k;
+    s->ov_choice = e ? 1 : -1;
+    s->nu_chunk = c ? max(1, atoi(c)) : max(1, min(16, 224 / ncol));
+    if (s->nu_overlap > 0) {
+      bool ok = hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess;
+      for (int a = 0; a < 2 && ok; ++a)
+        for (int b = 0; b < 2 && ok; ++b) ok = hipEventCreate(&s->ev_span[a][b]) == hipSuccess;
+      for (int i = 0; i < s->nu_overlap && ok; ++i) {
+        hipEvent_t ev;
+        ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        if (ok) s->ev_panel.push_back(ev);
+      }
+      if (!ok) { set_error("second stream: creation failed"); return fail(GPIRT_ERR_HIP); }
+    } else {
+      s->ov_choice = 0;
+    }
+  }
+  s->span_kind[0] = s->span_kind[1] = -1;
   if (cfg->theta_mode == GPIRT_THETA_GRID) {
     A_(s->d_onehot, (size_t)C * ML * Np_pad);
     A_(s->d_T, (size_t)G_pad * C * ML);
@@ -710,14 +760,84 @@ static int phase_factor_generator(gpirt_sampler *s, int *done) {
   return GPIRT_OK;
 }
 
+// nu = L z for every unit at once (sample_fs.m:2), rows [r0, r1) of it
+static GemmArgs nu_args(const gpirt_sampler *s, int r0, int r1) {
+  GemmArgs g{};
+  g.A = s->d_S + r0; g.lda = s->Np_pad; g.strideA = (int64_t)s->Np_pad * s->Np_pad;
+  g.B = s->d_Z; g.ldb = s->Np_pad; g.strideB = (int64_t)s->Np_pad * s->ML;
+  g.C = s->d_nu + r0; g.ldc = s->Np_pad; g.strideC = (int64_t)s->Np_pad * s->ML;
+  g.M = r1 - r0; g.N = s->ML; g.K = r1; g.batch = s->P; g.alpha = 1.0; g.beta = 0.0;
+  g.k_trim = 1; g.k_base = r0;
+  return g;
+}
+
+// Called by the factorisation when block columns [o, oe) are final and the trailing update
+// behind them is enqueued: whole chunks of final rows go to the second stream.
+static int nu_panel_hook(void *ctx, int o, int oe) {
+  gpirt_sampler *s = (gpirt_sampler *)ctx;
+  const int sp = o / 4, lim = min(s->nu_overlap * 4, s->nb);
+  if (sp >= s->nu_overlap) return GPIRT_OK;
+  const int avail = min(oe, lim);
+  bool recorded = false;
+  for (int t = s->nu_rows_done / TILE; t + s->nu_chunk <= avail || (avail == lim && t < lim);) {
+    const int t1 = min(t + s->nu_chunk, avail);
+    if (!recorded) {
+      GP_HIP(hipEventRecord(s->ev_panel[sp], s->st));
+      GP_HIP(hipStreamWaitEvent(s->st2, s->ev_panel[sp], 0));
+      recorded = true;
+    }
+    GP_TRY(launch_gemm(s->st2, false, false, nu_args(s, t * TILE, t1 * TILE)));
+    s->nu_rows_done = t1 * TILE;
+    t = t1;
+  }
+  return GPIRT_OK;
+}
+
+// The span measured in the sweep before this one is complete once this sweep's factorisation
+// has been waited for: sweeps 1 and 3 of the dense route are the measurements without and with
+// the rows beside the factorisation (0 and 2 warm each setting up), then the faster one stays.
+static int overlap_tune(gpirt_sampler *s) {
+  if (s->ov_choice >= 0) return GPIRT_OK;
+  const int prev = (s->dense_sweeps + 1) & 1, kind = s->span_kind[prev];
+  if (kind >= 0) {
+    float ms = 0;
+    GP_HIP(hipEventElapsedTime(&ms, s->ev_span[prev][0], s->ev_span[prev][1]));
+    s->ov_ms[kind] = ms;
+    s->span_kind[prev] = -1;
+    if (kind == 1) s->ov_choice = s->ov_ms[1] < 0.98f * s->ov_ms[0] ? 1 : 0;
+  }
+  return GPIRT_OK;
+}
+
+static int fill_z(gpirt_sampler *s) {
+  GP_TRY(mark(s, PH_Z));
+  GP_TRY(launch_fill_normal(s->st, s->d_Z, s->Np_pad, s->Np, s->Np_pad, s->U_pad, s->mloc, s->ML,
+                            s->m, s->j0, s->seed, s->sweep));
+  s->z_filled = 1;
+  return GPIRT_OK;
+}
+
 static int phase_factor(gpirt_sampler *s) {
   s->gen_now = 0;
+  s->z_filled = 0;
+  s->nu_rows_done = 0;
+  s->span_open = 0;
   if (s->gen_prior) {
     int done = 0;
     GP_TRY(phase_factor_generator(s, &done));
     if (done) { s->gen_now = 1; return GPIRT_OK; }
   }
+  s->ov_now = s->nu_overlap > 0 && (s->ov_choice >= 0 ? s->ov_choice : s->dense_sweeps >= 2);
+  const int par = s->dense_sweeps & 1;
+  if (s->ov_choice < 0) {
+    GP_HIP(hipEventRecord(s->ev_span[par][0], s->st));
+    s->span_kind[par] = s->dense_sweeps == 1 ? 0 : (s->dense_sweeps == 3 ? 1 : -1);
+    s->span_open = par + 1;
+  }
+  if (s->ov_now) GP_TRY(fill_z(s));
+  const PotrfHook hook{nu_panel_hook, s};
   for (;;) {
+    s->nu_rows_done = 0;
     GP_TRY(mark(s, PH_KBUILD));
     GP_TRY(launch_k_build(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
                           s->cfg.irf_sf, s->jitter_now, s->d_S, false));
@@ -731,7 +851,12 @@ static int phase_factor(gpirt_sampler *s) {
       GP_TRY(launch_bary(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->d_nodes, s->d_bw, s->fs_nodes,
                          s->cfg.grid_lo, s->cfg.grid_lo + s->cfg.grid_step * (s->G - 1), s->d_W,
                          (int64_t)s->Np_pad * s->G_pad, s->d_info + 1));
-    GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info, s->d_fwork));
+    GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info, s->d_fwork,
+                        s->ov_now ? &hook : nullptr));
+    if (s->nu_rows_done > 0) {   // the rows of nu computed beside the factorisation join the stream
+      GP_HIP(hipEventRecord(s->ev_join, s->st2));
+      GP_HIP(hipStreamWaitEvent(s->st, s->ev_join, 0));
+    }
     GP_HIP(hipMemcpyAsync(info3, s->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, s->st));
     GP_HIP(hipStreamSynchronize(s->st));
     if (info3[2]) {
@@ -740,7 +865,11 @@ static int phase_factor(gpirt_sampler *s) {
     }
     s->theta_inside = !info3[1];
     const int info = info3[0];
-    if (!info) return GPIRT_OK;
+    if (!info) {
+      GP_TRY(overlap_tune(s));
+      s->dense_sweeps++;
+      return GPIRT_OK;
+    }
     if (s->jitter_now >= 1e-2) {
       set_error("K(theta,theta)+%g I is not positive definite (pivot %d)", s->jitter_now, info);
       return GPIRT_ERR_NOT_PD;
@@ -751,18 +880,15 @@ static int phase_factor(gpirt_sampler *s) {
 }
 
 static int phase_f(gpirt_sampler *s) {
-  GP_TRY(mark(s, PH_Z));
-  GP_TRY(launch_fill_normal(s->st, s->d_Z, s->Np_pad, s->Np, s->Np_pad, s->U_pad, s->mloc, s->ML,
-                            s->m, s->j0, s->seed, s->sweep));
+  if (!s->z_filled) GP_TRY(fill_z(s));
   GP_TRY(mark(s, PH_NU));
-  GemmArgs g{};  // nu = L z for every unit at once (sample_fs.m:2)
-  g.A = s->d_S; g.lda = s->Np_pad; g.strideA = (int64_t)s->Np_pad * s->Np_pad;
-  g.B = s->d_Z; g.ldb = s->Np_pad; g.strideB = (int64_t)s->Np_pad * s->ML;
-  g.C = s->d_nu; g.ldc = s->Np_pad; g.strideC = (int64_t)s->Np_pad * s->ML;
-  g.M = s->Np_pad; g.N = s->ML; g.K = s->Np_pad; g.batch = s->P; g.alpha = 1.0; g.beta = 0.0;
+  // the rows that were not computed beside the factorisation (all of them by default)
+  const int r0 = s->gen_now ? 0 : s->nu_rows_done;
+  GemmArgs g = nu_args(s, r0, s->Np_pad);
   // the XCD-aware tile order keeps HBM traffic down when there are many column tiles per row
   // panel; with fewer it is slower than plain longest-first (3.83 vs 3.59 ms at 2048 columns)
-  g.k_trim = (s->Np_pad / TILE) * (s->ML / TILE) >= 2048 ? 3 : 1;
+  // (k_trim 4: longest-first under a kernel name of its own, so that a profile lists it apart)
+  g.k_trim = r0 > 0 ? 4 : ((g.M / TILE) * (s->ML / TILE) >= 2048 ? 3 : 1);
   if (s->gen_now) {
     // nu_b = L_bb z_b + Phi_b sum_{b' < b} W_b' z_b'  (phase_factor_generator)
     const int nblk = s->Np_pad / TILE;
@@ -794,6 +920,10 @@ static int phase_f(gpirt_sampler *s) {
                             s->d_nu, s->Np_pad));
   } else {
     GP_TRY(launch_gemm(s->st, false, false, g));
+  }
+  if (s->span_open) {
+    GP_HIP(hipEventRecord(s->ev_span[s->span_open - 1][1], s->st));
+    s->span_open = 0;
   }
   GP_TRY(mark(s, PH_ESSF));
   EssFArgs a{};
@@ -1145,6 +1275,7 @@ int gpirt_sampler_diagnostics(gpirt_sampler *s, gpirt_outputs *o) {
   o->ess_theta_rounds = s->theta_rounds;
   o->ess_capped = (int64_t)(c[1] + c[3] + c[5]);
   o->jitter_retries = s->jitter_retries;
+  o->nu_rows_beside_factor = s->gen_now ? 0 : s->nu_rows_done;
   return GPIRT_OK;
 }
 

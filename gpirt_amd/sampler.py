@@ -102,6 +102,13 @@ class Sampler:
                     ess_theta_rounds=o.ess_theta_rounds, ess_capped=o.ess_capped,
                     jitter_retries=o.jitter_retries)
 
+    def nu_rows_beside_factor(self):
+        """Rows of nu = L Z that the last sweep computed on the second stream beside the
+        factorisation (0: one launch after it)."""
+        o = _abi.GpirtOutputs()
+        check(lib().gpirt_sampler_diagnostics(self._h, C.byref(o)))
+        return int(o.nu_rows_beside_factor)
+
     def accumulate(self, quadratic=False):
         """Add the current state to the device-side running sums of the posterior summaries."""
         check(lib().gpirt_sampler_accumulate(self._h, int(bool(quadratic))))

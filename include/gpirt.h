@@ -75,6 +75,10 @@ enum {
   GPIRT_FSTAR_SOLVE = 64,  /* f* step: keep the interpolated cross-covariance but go through the
                               two triangular solves with the n x n factor instead of the low-rank
                               identity (see gpirt_sampler_sweep)                              */
+  GPIRT_NO_NU_OVERLAP = 256, /* compute nu = L Z in one launch after the factorisation; by default,
+                              from 4096 inputs on, the first rows of it are computed beside the
+                              factorisation on a second stream (same result bit for bit) when the
+                              sampler's own timing of its first sweeps finds that faster         */
   GPIRT_GENERATOR_PRIOR = 128 /* keep the Cholesky factor of K(theta,theta) + s2 I in generator
                               (block semiseparable) form instead of as an n x n matrix (see
                               gpirt_sampler_sweep); one IRF group only, ignored otherwise      */
@@ -147,7 +151,8 @@ typedef struct gpirt_outputs {
   int64_t ess_theta_rounds;   /* ... in the respondent step (lock-step rounds)          */
   int64_t ess_capped;         /* slice updates that hit max_ess_rounds (state kept)     */
   int32_t jitter_retries;     /* Cholesky retries with 10x jitter                       */
-  int32_t reserved;
+  int32_t nu_rows_beside_factor; /* rows of nu = L Z computed beside the factorisation in the
+                                    last sweep (0: one launch after it)                    */
   double seconds_total;       /* wall time inside the sweep loop                        */
 } gpirt_outputs;
 

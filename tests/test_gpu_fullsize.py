@@ -131,3 +131,33 @@ def test_sweep_invariants(flags):
         for k in key:
             # same decisions, values equal to the accuracy of the solves with K + 1e-6 I
             assert np.abs(st[k] - test_sweep_invariants.first[k]).max() < 1e-5, k
+
+
+def test_rows_of_nu_beside_the_factorisation_leave_the_chain_unchanged(monkeypatch):
+    """nu = L Z (elliptical_slice.m:64, sample_fs.m:2): the rows whose part of L is final may be
+    computed on a second stream while the factorisation goes on.  Same tiles, same arithmetic
+    per tile: six sweeps give the same chain bit for bit with the rows of 12 super-panels
+    computed that way (forced), with the sampler's own choice (it times both ways in its first
+    sweeps), and with one launch after the factorisation (GPIRT_NO_NU_OVERLAP)."""
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synth import generate
+    d = generate(N, M, C, seed=1)
+
+    def chain(flags, forced):
+        if forced is None:
+            monkeypatch.delenv("GPIRT_NU_OVERLAP", raising=False)
+        else:
+            monkeypatch.setenv("GPIRT_NU_OVERLAP", str(forced))
+        cfg = _abi.default_config(n=N, m=M, H=1, C=C, seed=3, flags=flags)
+        with Sampler(cfg, d["y"], theta_init=d["theta"]) as s:
+            s.sweep(6)
+            return s.state(fstar=False), s.nu_rows_beside_factor(), s.diagnostics()
+
+    base, rows0, dg0 = chain(_abi.NO_NU_OVERLAP, None)
+    forced, rows1, dg1 = chain(0, 12)
+    own, rows2, dg2 = chain(0, None)
+    assert rows0 == 0 and rows1 == 12 * 512 and rows2 in (0, 6144)
+    assert dg0 == dg1 == dg2
+    for k in ("theta", "f", "beta"):
+        assert np.array_equal(base[k], forced[k]), k
+        assert np.array_equal(base[k], own[k]), k
