@@ -228,8 +228,15 @@ def main():
 
     # the sampler times its first five sweeps of the dense route to choose between computing the
     # first rows of nu = L*Z beside the factorisation or after it (same chain bit for bit):
-    # that choice is part of the set-up, before the warm-up steps
-    s.sweep(SETUP_SWEEPS)
+    # that choice is part of the set-up, before the warm-up steps.  Its second sweep still runs
+    # the whole product as one launch after the factorisation: that launch's time is kept for
+    # the roofline report.
+    s.sweep(1)
+    pa = s.phase_times()
+    s.sweep(1)
+    pb = s.phase_times()
+    nu_alone_ms = pb["nu"][0] - pa["nu"][0] if s.nu_rows_beside_factor() == 0 else None
+    s.sweep(SETUP_SWEEPS - 2)
     s.sweep(args.warmup)
     ph0 = s.phase_times()
     d0 = s.diagnostics()
@@ -334,6 +341,18 @@ def main():
             "likelihood_evals_per_step": evals,
             "diagnostics": d1,
         }
+        if r0 > 0:
+            out["roofline"]["note"] = (
+                "rows %d..%d of nu = L*Z are what is left after the factorisation: at most 512 tiles, one "
+                "round of workgroups with the longest K, while the chunks of earlier rows that lag behind "
+                "the factorisation finish beside it on the second stream" % (r0, n))
+            if nu_alone_ms:
+                whole = float(n) * n * mloc / (nu_alone_ms * 1e-3) / 1e12
+                out["roofline"]["whole_product_in_one_launch"] = {
+                    "kernel": "gemm_f64_kernel<false,false,4>, sweep 2 of the set-up (no rows beside the factorisation)",
+                    "ms_per_launch": nu_alone_ms, "flop_per_launch": float(n) * n * mloc,
+                    "achieved": whole, "frac": whole / FP64_MFMA_PEAK_TFLOPS,
+                    "traffic": pmc_traffic(n, m, world, 0)}
         if variant is not None:
             out["variants"] = {"generator_prior": variant}
         if world == 1 and not args.no_cpu_baseline:

@@ -142,7 +142,7 @@ struct gpirt_sampler {
   // times the factor + nu span with and without it in its first sweeps and keeps the faster.
   hipStream_t st2;
   std::vector<hipEvent_t> ev_panel;
-  hipEvent_t ev_join, ev_span[2][2];   // [sweep parity][begin, end] of the factor + nu span
+  hipEvent_t ev_join, ev_z, ev_span[2][2];   // [sweep parity][begin, end] of the factor + nu span
   int nu_overlap, nu_chunk, nu_rows_done, z_filled;
   int ov_now;          // this sweep computes rows beside the factorisation
   int ov_choice;       // -1: still measuring; 0 / 1: decided (or forced)
@@ -167,6 +167,7 @@ static void sampler_free(gpirt_sampler *s) {
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_panel) (void)hipEventDestroy(e);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+  if (s->ev_z) (void)hipEventDestroy(s->ev_z);
   for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) if (s->ev_span[a][b]) (void)hipEventDestroy(s->ev_span[a][b]);
   if (s->st2) (void)hipStreamDestroy(s->st2);
   if (s->st) (void)hipStreamDestroy(s->st);
@@ -537,18 +538,19 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   s->ov_choice = 0;
   if (s->nu_splits == 1 && Np_pad >= 8 * SUP && !(cfg->flags & GPIRT_NO_NU_OVERLAP)) {
     // GPIRT_NU_OVERLAP=k forces k super-panels (0: none) and GPIRT_NU_CHUNK=t the chunk size;
-    // by default about 0.6 of the rows, cut so that the rows left for the launch after the
-    // factorisation make just under 1024 tiles (two full rounds of workgroups)
+    // by default the rows left for the launch after the factorisation make at most 512 tiles
+    // (one round of workgroups: those rows have the longest K, a tile of them runs ~2 ms)
     const int nsup = inv_nsup(Np_pad), ncol = ML / TILE;
     const char *e = getenv("GPIRT_NU_OVERLAP"), *c = getenv("GPIRT_NU_CHUNK");
-    int k = (s->nb - 1024 / ncol + 3) / 4;
-    k = max((nsup + 1) / 2, min(k, nsup * 3 / 4));
+    int k = (s->nb - 512 / ncol + 3) / 4;
+    k = max((nsup + 1) / 2, min(k, nsup - 2));
     s->nu_overlap = e ? min(atoi(e), nsup) : k;
     s->ov_choice = e ? 1 : -1;
     s->nu_chunk = c ? max(1, atoi(c)) : max(1, min(16, 224 / ncol));
     if (s->nu_overlap > 0) {
       bool ok = hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking) == hipSuccess &&
-                hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess;
+                hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&s->ev_z, hipEventDisableTiming) == hipSuccess;
       for (int a = 0; a < 2 && ok; ++a)
         for (int b = 0; b < 2 && ok; ++b) ok = hipEventCreate(&s->ev_span[a][b]) == hipSuccess;
       for (int i = 0; i < s->nu_overlap && ok; ++i) {
@@ -834,13 +836,24 @@ static int phase_factor(gpirt_sampler *s) {
     s->span_kind[par] = s->dense_sweeps == 1 ? 0 : (s->dense_sweeps == 3 ? 1 : -1);
     s->span_open = par + 1;
   }
-  if (s->ov_now) GP_TRY(fill_z(s));
   const PotrfHook hook{nu_panel_hook, s};
   for (;;) {
     s->nu_rows_done = 0;
     GP_TRY(mark(s, PH_KBUILD));
     GP_TRY(launch_k_build(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
                           s->cfg.irf_sf, s->jitter_now, s->d_S, false));
+    if (s->ov_now && !s->z_filled) {
+      // the normal draws depend on nothing but the sweep counter: they run on the second stream,
+      // ahead of the chunks that read them, beside the first super-panel's chain of small kernels
+      // (beside the kernel-matrix build they would share its HBM bandwidth); the join event is
+      // free here, and the wait keeps them behind the previous sweep's launches that read Z
+      GP_HIP(hipEventRecord(s->ev_join, s->st));
+      GP_HIP(hipStreamWaitEvent(s->st2, s->ev_join, 0));
+      GP_TRY(launch_fill_normal(s->st2, s->d_Z, s->Np_pad, s->Np, s->Np_pad, s->U_pad, s->mloc, s->ML,
+                                s->m, s->j0, s->seed, s->sweep));
+      GP_HIP(hipEventRecord(s->ev_z, s->st2));
+      s->z_filled = 1;
+    }
     GP_TRY(mark(s, PH_POTRF));
     // info[0]: pivot of a failed factorisation; [1]: an input outside the range of the f*
     // nodes; [2]: the 128 x 128 factorisation of the previous sweep's low-rank f* step
@@ -853,10 +866,6 @@ static int phase_factor(gpirt_sampler *s) {
                          (int64_t)s->Np_pad * s->G_pad, s->d_info + 1));
     GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info, s->d_fwork,
                         s->ov_now ? &hook : nullptr));
-    if (s->nu_rows_done > 0) {   // the rows of nu computed beside the factorisation join the stream
-      GP_HIP(hipEventRecord(s->ev_join, s->st2));
-      GP_HIP(hipStreamWaitEvent(s->st, s->ev_join, 0));
-    }
     GP_HIP(hipMemcpyAsync(info3, s->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, s->st));
     GP_HIP(hipStreamSynchronize(s->st));
     if (info3[2]) {
@@ -881,6 +890,7 @@ static int phase_factor(gpirt_sampler *s) {
 
 static int phase_f(gpirt_sampler *s) {
   if (!s->z_filled) GP_TRY(fill_z(s));
+  else if (s->ov_now && !s->gen_now) GP_HIP(hipStreamWaitEvent(s->st, s->ev_z, 0));   // drawn on the second stream
   GP_TRY(mark(s, PH_NU));
   // the rows that were not computed beside the factorisation (all of them by default)
   const int r0 = s->gen_now ? 0 : s->nu_rows_done;
@@ -920,6 +930,12 @@ static int phase_f(gpirt_sampler *s) {
                             s->d_nu, s->Np_pad));
   } else {
     GP_TRY(launch_gemm(s->st, false, false, g));
+  }
+  if (s->ov_now && !s->gen_now) {
+    // the chunks that lag behind the factorisation run on beside the launch above (disjoint rows);
+    // everything on the second stream joins before the slice step reads nu
+    GP_HIP(hipEventRecord(s->ev_join, s->st2));
+    GP_HIP(hipStreamWaitEvent(s->st, s->ev_join, 0));
   }
   if (s->span_open) {
     GP_HIP(hipEventRecord(s->ev_span[s->span_open - 1][1], s->st));

@@ -156,7 +156,7 @@ def test_rows_of_nu_beside_the_factorisation_leave_the_chain_unchanged(monkeypat
     base, rows0, dg0 = chain(_abi.NO_NU_OVERLAP, None)
     forced, rows1, dg1 = chain(0, 12)
     own, rows2, dg2 = chain(0, None)
-    assert rows0 == 0 and rows1 == 12 * 512 and rows2 in (0, 6144)
+    assert rows0 == 0 and rows1 == 12 * 512 and rows2 in (0, 16 * 512)
     assert dg0 == dg1 == dg2
     for k in ("theta", "f", "beta"):
         assert np.array_equal(base[k], forced[k]), k
