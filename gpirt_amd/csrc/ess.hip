@@ -148,6 +148,30 @@ __device__ inline double unit_sum(double acc, double *red, int w) {
   return (red[0] + red[1]) + (red[2] + red[3]);   // fixed order: identical in every wave
 }
 
+// A proposal is accepted when its log-likelihood exceeds the slice height hh
+// (elliptical_slice.m:87).  Every cell adds log p <= 0, so the sum over the rows done so far
+// bounds the final sum from above, and the running product's exponents bound that in turn
+// (mantissas lie in [1/2, 1)):  sum so far < ln2 * (sum of the lanes' exponents).  Once this
+// integer bound is at or below hh the proposal is rejected whatever the remaining rows hold,
+// and the pass stops there: same decision, most of a far-off proposal's rows never evaluated.
+// Checked every SLICE_CHECK iterations; uniform over the unit's waves.  The waves exchange
+// their sums through one of two slots, alternating from check to check: a wave can only write
+// a slot again after the barrier of the check in between, which every wave passes after its
+// reads of that slot.
+constexpr int SLICE_CHECK = 4;
+template <int WPU>
+__device__ inline bool surely_rejected(int e, double hh, int *redi, int w) {
+  int v = e;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if (WPU != 1) {
+    if ((threadIdx.x & 63) == 0) redi[w] = v;
+    __syncthreads();
+    v = (redi[0] + redi[1]) + (redi[2] + redi[3]);
+  }
+  return (double)v * 0.69314718055994530942 <= hh;
+}
+
 // ---------------------------------------------------------------------------------------
 // slice update of f (a4 + a5)
 // ---------------------------------------------------------------------------------------
@@ -156,25 +180,30 @@ __device__ inline double ll_f_pass(const double *__restrict__ f, const double *_
                                    const double *__restrict__ mu, const double *__restrict__ x,
                                    double b0, double b1, double b2, const int8_t *__restrict__ y,
                                    const double *sb, const double *sphi, int n, int row0, double c,
-                                   double s, double *red, int w) {
+                                   double s, double *red, int w, double hh, int (*redi)[WPB], int &cp) {
   // Software-pipelined and branch-free: the loads of the next row are in flight while the
   // current cell is evaluated (a wave that waits for y before it asks for f pays two memory
   // round trips per row, and four waves per SIMD do not hide that).  Indices past the end
   // are clamped to the last row and their cells masked out.
   LogProduct prod;
   prod.reset();
-  if (row0 >= n) return unit_sum<WPU>(0.0, red, w);
-  int yy = y[row0];
-  double fr = f[row0], nr = nu[row0], xr = mu ? mu[row0] : x[row0];
-  for (int r = row0; r < n; r += 64 * WPU) {
-    const int rn = min(r + 64 * WPU, n - 1);
+  const int stride = 64 * WPU, iters = (n + stride - 1) / stride;   // uniform over the unit
+  const int rc = min(row0, n - 1);
+  int yy = y[rc];
+  double fr = f[rc], nr = nu[rc], xr = mu ? mu[rc] : x[rc];
+  int r = row0;
+  for (int it = 0; it < iters; ++it, r += stride) {
+    const int rn = min(r + stride, n - 1);
     const int yn = y[rn];
     const double fn = f[rn], nn = nu[rn], xn = mu ? mu[rn] : x[rn];
     const double m_r = mu ? xr : b0 + b1 * xr + b2 * xr * xr;
     const double gg = m_r + (fr * c + nr * s);
     const int yc = max(yy, 1);
     const double p = ordinal_cell_prob(sb[yc - 1] - gg, sb[yc] - gg, sphi);
-    prod.mul(yy > 0 ? p : 1.0);
+    prod.mul(yy > 0 && r < n ? p : 1.0);
+    if ((it & (SLICE_CHECK - 1)) == SLICE_CHECK - 1 && it + 1 < iters && hh > -INFINITY &&
+        surely_rejected<WPU>(prod.e, hh, redi[cp++ & 1], w))
+      return -INFINITY;
     yy = yn; fr = fn; nr = nn; xr = xn;
   }
   return unit_sum<WPU>(prod.log_value(), red, w);
@@ -185,8 +214,10 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
   __shared__ double sbb[WPB][MAXC + 2];
   __shared__ double sphi[PHI_LDS_DOUBLES];
   __shared__ double red[WPB];
+  __shared__ int redi[2][WPB];
   phi_table_to_lds(sphi);
   __syncthreads();
+  int cp = 0;   // checks so far: consecutive checks alternate between the two exchange slots
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int u = WPU == 1 ? blockIdx.x * WPB + w : blockIdx.x;
   if (u >= a.U_pad || u % a.ML >= a.mloc) return;    // uniform over the workgroup when WPU = 4
@@ -209,7 +240,8 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
     return un ? un[d] : rng_uniform_at(a.seed, TAG_F_U, a.sweep, ug, (uint32_t)d);
   };
 
-  const double cur = ll_f_pass<WPU>(f, nu, mu, x, b0, b1, b2, y, sb, sphi, n, row0, 1.0, 0.0, red, w);
+  const double cur = ll_f_pass<WPU>(f, nu, mu, x, b0, b1, b2, y, sb, sphi, n, row0, 1.0, 0.0, red, w,
+                                    -INFINITY, redi, cp);
   const double hh = log(draw(0)) + cur;              // elliptical_slice.m:66
   double phi = draw(1) * kTwoPi;                     // :72
   double pmin = phi - kTwoPi, pmax = phi;            // :73-74
@@ -218,7 +250,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
   double l = cur, c = 1.0, s = 0.0;
   while (r < a.R) {
     sincos(phi, &s, &c);
-    l = ll_f_pass<WPU>(f, nu, mu, x, b0, b1, b2, y, sb, sphi, n, row0, c, s, red, w);  // :85-86
+    l = ll_f_pass<WPU>(f, nu, mu, x, b0, b1, b2, y, sb, sphi, n, row0, c, s, red, w, hh, redi, cp);  // :85-86
     ++r;
     if (l > hh) { ok = true; break; }                // :87
     if (phi > 0.0) pmax = phi;                       // :92-96
@@ -276,20 +308,26 @@ template <int WPU>
 __device__ inline double ll_param_pass(const double *__restrict__ f, const double *__restrict__ x,
                                        double b0, double b1, double b2,
                                        const int8_t *__restrict__ y, const double *sb,
-                                       const double *sphi, int n, int row0, double *red, int w) {
-  LogProduct prod;                       // pipelined like ll_f_pass
+                                       const double *sphi, int n, int row0, double *red, int w,
+                                       double hh, int (*redi)[WPB], int &cp) {
+  LogProduct prod;                       // pipelined like ll_f_pass, same early rejection
   prod.reset();
-  if (row0 >= n) return unit_sum<WPU>(0.0, red, w);
-  int yy = y[row0];
-  double fr = f[row0], xr = x[row0];
-  for (int r = row0; r < n; r += 64 * WPU) {
-    const int rn = min(r + 64 * WPU, n - 1);
+  const int stride = 64 * WPU, iters = (n + stride - 1) / stride;
+  const int rc = min(row0, n - 1);
+  int yy = y[rc];
+  double fr = f[rc], xr = x[rc];
+  int r = row0;
+  for (int it = 0; it < iters; ++it, r += stride) {
+    const int rn = min(r + stride, n - 1);
     const int yn = y[rn];
     const double fn = f[rn], xn = x[rn];
     const double gg = b0 + b1 * xr + b2 * xr * xr + fr;
     const int yc = max(yy, 1);
     const double p = ordinal_cell_prob(sb[yc - 1] - gg, sb[yc] - gg, sphi);
-    prod.mul(yy > 0 ? p : 1.0);
+    prod.mul(yy > 0 && r < n ? p : 1.0);
+    if ((it & (SLICE_CHECK - 1)) == SLICE_CHECK - 1 && it + 1 < iters && hh > -INFINITY &&
+        surely_rejected<WPU>(prod.e, hh, redi[cp++ & 1], w))
+      return -INFINITY;
     yy = yn; fr = fn; xr = xn;
   }
   return unit_sum<WPU>(prod.log_value(), red, w);
@@ -300,8 +338,10 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
   __shared__ double sbb[WPB][MAXC + 2];
   __shared__ double sphi[PHI_LDS_DOUBLES];
   __shared__ double red[WPB];
+  __shared__ int redi[2][WPB];
   phi_table_to_lds(sphi);
   __syncthreads();
+  int cp = 0;   // checks so far: consecutive checks alternate between the two exchange slots
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int u = WPU == 1 ? blockIdx.x * WPB + w : blockIdx.x;
   if (u >= a.U_pad || u % a.ML >= a.mloc) return;    // uniform over the workgroup when WPU = 4
@@ -333,7 +373,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
   if (WPU != 1) __syncthreads();          // the thresholds every wave just wrote (same values)
   // the slice update of f that ran just before left the log-likelihood of exactly this state
   const double cur = a.ll_in ? a.ll_in[u]
-                             : ll_param_pass<WPU>(f, x, b0, b1, b2, y, sb, sphi, n, row0, red, w);
+                             : ll_param_pass<WPU>(f, x, b0, b1, b2, y, sb, sphi, n, row0, red, w, -INFINITY, redi, cp);
   int r = 0;
   bool ok = false;
   double l = cur;
@@ -351,7 +391,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
       }
       params_from_white(pv, pm, ps, C, b0, b1, b2, sb);
       if (WPU != 1) __syncthreads();
-      l = ll_param_pass<WPU>(f, x, b0, b1, b2, y, sb, sphi, n, row0, red, w);
+      l = ll_param_pass<WPU>(f, x, b0, b1, b2, y, sb, sphi, n, row0, red, w, hh, redi, cp);
       ++r;
       if (l > hh) { ok = true; break; }
       if (phi > 0.0) pmax = phi;
