@@ -171,8 +171,11 @@ inline int64_t potrf_work_elems(int n_pad, int batch) {
 // [o, oe) and the trailing update behind them have been enqueued: from then on (in stream order)
 // rows [o*TILE, oe*TILE) of L are final and the chain of small kernels of the next block columns begins.
 struct PotrfHook { int (*fn)(void *ctx, int o, int oe); void *ctx; };
+// With defer_super_inverses the off-diagonal blocks of the inverted super-blocks, which only the
+// triangular solves (launch_potrs) read, are left to a later launch_super_inverses call.
 int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, int *d_info,
-                 double *work, const PotrfHook *hook = nullptr);
+                 double *work, const PotrfHook *hook = nullptr, bool defer_super_inverses = false);
+int launch_super_inverses(hipStream_t st, const double *L, int n_pad, int batch, double *inv, double *work);
 // B <- S^-1 B (two blocked triangular solves) for `batch` systems sharing the layout;
 // xtmp holds 4 * SUP * nrhs_pad doubles per system (split-K slabs of the diagonal steps).
 int launch_potrs(hipStream_t st, const double *L, const double *inv, int n_pad, int batch,

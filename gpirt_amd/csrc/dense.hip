@@ -594,8 +594,16 @@ static int build_super_inverses(hipStream_t st, const double *L, int n_pad, doub
 // next diagonal step beside a trailing update on a second stream was measured and is not
 // faster: the one-workgroup diagonal kernel needs a whole CU's LDS and only starts when the
 // update, which fills every CU, drains.
+int launch_super_inverses(hipStream_t st, const double *L, int n_pad, int batch, double *inv, double *work) {
+  if (n_pad / TILE > 1)
+    for (int z = 0; z < batch; ++z)
+      GP_TRY(build_super_inverses(st, L + (int64_t)n_pad * n_pad * z, n_pad, inv + inv_group_elems(n_pad) * z,
+                                  work + (int64_t)inv_nsup(n_pad) * 256 * 256 * z));
+  return GPIRT_OK;
+}
+
 int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, int *d_info,
-                 double *work, const PotrfHook *hook) {
+                 double *work, const PotrfHook *hook, bool defer_super_inverses) {
   const int nb = n_pad / TILE;
   const int64_t sS = (int64_t)n_pad * n_pad, sI = inv_group_elems(n_pad);
   auto panel_solve = [&](int k) -> int {   // L_ik = A_ik * inv(L_kk)^T, i > k
@@ -636,10 +644,7 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
     }
     if (hook) GP_TRY(hook->fn(hook->ctx, o, oe));
   }
-  if (nb > 1)
-    for (int z = 0; z < batch; ++z)
-      GP_TRY(build_super_inverses(st, S + sS * z, n_pad, inv + sI * z,
-                                  work + (int64_t)inv_nsup(n_pad) * 256 * 256 * z));
+  if (!defer_super_inverses) GP_TRY(launch_super_inverses(st, S, n_pad, batch, inv, work));
   return GPIRT_OK;
 }
 

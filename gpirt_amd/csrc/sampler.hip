@@ -121,6 +121,7 @@ struct gpirt_sampler {
   double *d_Jb, *d_jinv, *d_Tb, *d_Sbb, *d_linv, *d_Et, *d_Wt, *d_V;
   int gen_prior;             // the route is set up
   int gen_now;               // this sweep's factor is in generator form
+  int super_inv_ready;       // the off-diagonal blocks of this sweep's inverted super-blocks are built
   int theta_inside;          // this sweep's inputs all lie inside the nodes' range
   int fs_nodes, fs_rank;     // nodes in use and their padded count (0: exact cross-covariance)
   int summary_draws;
@@ -865,7 +866,8 @@ static int phase_factor(gpirt_sampler *s) {
                          s->cfg.grid_lo, s->cfg.grid_lo + s->cfg.grid_step * (s->G - 1), s->d_W,
                          (int64_t)s->Np_pad * s->G_pad, s->d_info + 1));
     GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info, s->d_fwork,
-                        s->ov_now ? &hook : nullptr));
+                        s->ov_now ? &hook : nullptr, true));
+    s->super_inv_ready = 0;
     GP_HIP(hipMemcpyAsync(info3, s->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, s->st));
     GP_HIP(hipStreamSynchronize(s->st));
     if (info3[2]) {
@@ -967,6 +969,14 @@ static int phase_param(gpirt_sampler *s) {
   return GPIRT_OK;
 }
 
+// the triangular solves with the n x n factor need the whole inverted super-blocks; the default
+// f* route never solves with it, so they are built only when a sweep gets here
+static int ensure_super_inverses(gpirt_sampler *s) {
+  if (s->super_inv_ready) return GPIRT_OK;
+  s->super_inv_ready = 1;
+  return launch_super_inverses(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_fwork);
+}
+
 static int phase_fstar(gpirt_sampler *s) {
   GP_TRY(mark(s, PH_FSTAR));
   // f*^T = F^T S^-1 K(x, xs)   (gp posterior mean, main.m:57-58).  The solve goes to whichever
@@ -1010,6 +1020,7 @@ static int phase_fstar(gpirt_sampler *s) {
       GP_TRY(launch_kstar_nodes(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
                                 s->cfg.irf_sf, s->d_nodes, s->fs_nodes, R, s->d_W,
                                 (int64_t)s->Np_pad * s->G_pad));
+      GP_TRY(ensure_super_inverses(s));
       GP_TRY(launch_potrs(s->st, s->d_S, s->d_inv, s->Np_pad, s->P, s->d_W, s->Np_pad,
                           (int64_t)s->Np_pad * s->G_pad, R, s->d_xtmp));
     }
@@ -1053,10 +1064,12 @@ static int phase_fstar(gpirt_sampler *s) {
     // nu is free between the f step and the next sweep: alpha is built there
     GP_HIP(hipMemcpyAsync(s->d_nu, s->d_f, sizeof(double) * (size_t)s->Np_pad * s->U_pad,
                           hipMemcpyDeviceToDevice, s->st));
+    GP_TRY(ensure_super_inverses(s));
     GP_TRY(launch_potrs(s->st, s->d_S, s->d_inv, s->Np_pad, s->P, s->d_nu, s->Np_pad,
                         (int64_t)s->Np_pad * s->ML, s->ML, s->d_xtmp));
     lhs = s->d_nu;
   } else {
+    GP_TRY(ensure_super_inverses(s));
     GP_TRY(launch_potrs(s->st, s->d_S, s->d_inv, s->Np_pad, s->P, s->d_W, s->Np_pad,
                         (int64_t)s->Np_pad * s->G_pad, s->G_pad, s->d_xtmp));
   }
