@@ -143,7 +143,8 @@ struct gpirt_sampler {
   // times the factor + nu span with and without it in its first sweeps and keeps the faster.
   hipStream_t st2;
   std::vector<hipEvent_t> ev_panel;
-  hipEvent_t ev_join, ev_z, ev_span[2][2];   // [sweep parity][begin, end] of the factor + nu span
+  hipEvent_t ev_join, ev_z, ev_pref, ev_span[2][2];
+  int pref_on_st2;     // this sweep's input-only factors of the low-rank f* step went to the second stream   // [sweep parity][begin, end] of the factor + nu span
   int nu_overlap, nu_chunk, nu_rows_done, z_filled;
   int ov_now;          // this sweep computes rows beside the factorisation
   int ov_choice;       // -1: still measuring; 0 / 1: decided (or forced)
@@ -169,6 +170,7 @@ static void sampler_free(gpirt_sampler *s) {
   for (hipEvent_t e : s->ev_panel) (void)hipEventDestroy(e);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->ev_z) (void)hipEventDestroy(s->ev_z);
+  if (s->ev_pref) (void)hipEventDestroy(s->ev_pref);
   for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) if (s->ev_span[a][b]) (void)hipEventDestroy(s->ev_span[a][b]);
   if (s->st2) (void)hipStreamDestroy(s->st2);
   if (s->st) (void)hipStreamDestroy(s->st);
@@ -551,7 +553,8 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     if (s->nu_overlap > 0) {
       bool ok = hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking) == hipSuccess &&
                 hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&s->ev_z, hipEventDisableTiming) == hipSuccess;
+                hipEventCreateWithFlags(&s->ev_z, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&s->ev_pref, hipEventDisableTiming) == hipSuccess;
       for (int a = 0; a < 2 && ok; ++a)
         for (int b = 0; b < 2 && ok; ++b) ok = hipEventCreate(&s->ev_span[a][b]) == hipSuccess;
       for (int i = 0; i < s->nu_overlap && ok; ++i) {
@@ -825,6 +828,7 @@ static int phase_factor(gpirt_sampler *s) {
   s->z_filled = 0;
   s->nu_rows_done = 0;
   s->span_open = 0;
+  s->pref_on_st2 = 0;
   if (s->gen_prior) {
     int done = 0;
     GP_TRY(phase_factor_generator(s, &done));
@@ -890,6 +894,8 @@ static int phase_factor(gpirt_sampler *s) {
   }
 }
 
+static int fstar_lowrank_prefactor(gpirt_sampler *s, hipStream_t q);
+
 static int phase_f(gpirt_sampler *s) {
   if (!s->z_filled) GP_TRY(fill_z(s));
   else if (s->ov_now && !s->gen_now) GP_HIP(hipStreamWaitEvent(s->st, s->ev_z, 0));   // drawn on the second stream
@@ -938,6 +944,12 @@ static int phase_f(gpirt_sampler *s) {
     // everything on the second stream joins before the slice step reads nu
     GP_HIP(hipEventRecord(s->ev_join, s->st2));
     GP_HIP(hipStreamWaitEvent(s->st, s->ev_join, 0));
+    if (s->fs_lowrank && s->theta_inside && s->fs_rank > 0) {
+      // behind the join: the slice kernels do not wait for it, the f* step does
+      GP_TRY(fstar_lowrank_prefactor(s, s->st2));
+      GP_HIP(hipEventRecord(s->ev_pref, s->st2));
+      s->pref_on_st2 = 1;
+    }
   }
   if (s->span_open) {
     GP_HIP(hipEventRecord(s->ev_span[s->span_open - 1][1], s->st));
@@ -969,6 +981,38 @@ static int phase_param(gpirt_sampler *s) {
   return GPIRT_OK;
 }
 
+// The part of the low-rank f* step that depends on the inputs only (see setup_fstar_lowrank):
+// Phi = P B with sqrt(s2) I appended, its Gram matrix M = s2 I + Phi^T Phi in 128-deep slabs, the
+// factor of M and X = M^-1 B^T Lag.  Enqueued on q.
+static int fstar_lowrank_prefactor(gpirt_sampler *s, hipStream_t q) {
+  const int64_t ldp = s->Np_pad + TILE;
+  // Phi = P B, with sqrt(s2) I appended below so that its Gram matrix carries the s2 I
+  GemmArgs a{};
+  a.A = s->d_W; a.lda = s->Np_pad; a.strideA = (int64_t)s->Np_pad * s->G_pad;
+  a.B = s->d_B; a.ldb = s->fs_nodes; a.strideB = 0;
+  a.C = s->d_feat; a.ldc = ldp; a.strideC = ldp * TILE;
+  a.M = s->Np_pad; a.N = TILE; a.K = s->fs_nodes; a.batch = s->P; a.alpha = 1.0; a.beta = 0.0;
+  GP_TRY(launch_gemm(q, false, false, a));
+  GP_TRY(launch_scaled_identity(q, s->d_feat, ldp, s->Np_pad, s->P, ldp * TILE, sqrt(s->jitter_now)));
+  const int nslab = (int)(ldp / TILE);
+  for (int p = 0; p < s->P; ++p) {     // M = Phi^T Phi, K in 128-deep slabs side by side
+    GemmArgs m{};
+    m.A = s->d_feat + ldp * TILE * p; m.lda = ldp; m.strideA = TILE;
+    m.B = m.A; m.ldb = ldp; m.strideB = TILE;
+    m.C = s->d_gparts; m.ldc = TILE; m.strideC = TILE * TILE;
+    m.M = TILE; m.N = TILE; m.K = TILE; m.batch = nslab; m.alpha = 1.0; m.beta = 0.0;
+    GP_TRY(launch_gemm(q, true, false, m));
+    GP_TRY(launch_sum_slabs(q, s->d_gparts, nslab, TILE * TILE, TILE, TILE, TILE,
+                            s->d_Mm + (int64_t)TILE * TILE * p, TILE));
+    GP_HIP(hipMemcpyAsync(s->d_X + (int64_t)TILE * s->G_pad * p, s->d_BL,
+                          sizeof(double) * (size_t)TILE * s->G_pad, hipMemcpyDeviceToDevice, q));
+  }
+  GP_TRY(launch_potrf(q, s->d_Mm, TILE, s->P, s->d_minv, s->d_info + 2, s->d_fwork));
+  GP_TRY(launch_potrs(q, s->d_Mm, s->d_minv, TILE, s->P, s->d_X, TILE, (int64_t)TILE * s->G_pad,
+                      s->G_pad, s->d_xtmp));
+  return GPIRT_OK;
+}
+
 // the triangular solves with the n x n factor need the whole inverted super-blocks; the default
 // f* route never solves with it, so they are built only when a sweep gets here
 static int ensure_super_inverses(gpirt_sampler *s) {
@@ -990,31 +1034,10 @@ static int phase_fstar(gpirt_sampler *s) {
     const bool lowrank = s->fs_lowrank && s->theta_inside;
     const int64_t ldp = s->Np_pad + TILE;
     if (lowrank) {
-      // f*^T = (F^T Phi) (s2 I + Phi^T Phi)^-1 (B^T Lag), see setup_fstar_lowrank.
-      // Phi = P B, with sqrt(s2) I appended below so that its Gram matrix carries the s2 I
-      GemmArgs a{};
-      a.A = s->d_W; a.lda = s->Np_pad; a.strideA = (int64_t)s->Np_pad * s->G_pad;
-      a.B = s->d_B; a.ldb = s->fs_nodes; a.strideB = 0;
-      a.C = s->d_feat; a.ldc = ldp; a.strideC = ldp * TILE;
-      a.M = s->Np_pad; a.N = TILE; a.K = s->fs_nodes; a.batch = s->P; a.alpha = 1.0; a.beta = 0.0;
-      GP_TRY(launch_gemm(s->st, false, false, a));
-      GP_TRY(launch_scaled_identity(s->st, s->d_feat, ldp, s->Np_pad, s->P, ldp * TILE, sqrt(s->jitter_now)));
-      const int nslab = (int)(ldp / TILE);
-      for (int p = 0; p < s->P; ++p) {     // M = Phi^T Phi, K in 128-deep slabs side by side
-        GemmArgs m{};
-        m.A = s->d_feat + ldp * TILE * p; m.lda = ldp; m.strideA = TILE;
-        m.B = m.A; m.ldb = ldp; m.strideB = TILE;
-        m.C = s->d_gparts; m.ldc = TILE; m.strideC = TILE * TILE;
-        m.M = TILE; m.N = TILE; m.K = TILE; m.batch = nslab; m.alpha = 1.0; m.beta = 0.0;
-        GP_TRY(launch_gemm(s->st, true, false, m));
-        GP_TRY(launch_sum_slabs(s->st, s->d_gparts, nslab, TILE * TILE, TILE, TILE, TILE,
-                                s->d_Mm + (int64_t)TILE * TILE * p, TILE));
-        GP_HIP(hipMemcpyAsync(s->d_X + (int64_t)TILE * s->G_pad * p, s->d_BL,
-                              sizeof(double) * (size_t)TILE * s->G_pad, hipMemcpyDeviceToDevice, s->st));
-      }
-      GP_TRY(launch_potrf(s->st, s->d_Mm, TILE, s->P, s->d_minv, s->d_info + 2, s->d_fwork));
-      GP_TRY(launch_potrs(s->st, s->d_Mm, s->d_minv, TILE, s->P, s->d_X, TILE, (int64_t)TILE * s->G_pad,
-                          s->G_pad, s->d_xtmp));
+      // f*^T = (F^T Phi) (s2 I + Phi^T Phi)^-1 (B^T Lag); the factors that depend on the inputs
+      // only are ready when they were enqueued on the second stream beside the slice kernels
+      if (s->pref_on_st2) GP_HIP(hipStreamWaitEvent(s->st, s->ev_pref, 0));
+      else GP_TRY(fstar_lowrank_prefactor(s, s->st));
       R = TILE;
     } else {
       GP_TRY(launch_kstar_nodes(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
