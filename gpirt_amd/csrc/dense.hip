@@ -248,6 +248,9 @@ __global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs g, int nbn)
   constexpr bool AK = AT, BKC = !BT;
   __shared__ __attribute__((aligned(16))) double sA[ChunkImage<AK>::SIZE];
   __shared__ __attribute__((aligned(16))) double sB[ChunkImage<BKC>::SIZE];
+  // these launches sit on the factorisation's critical path and may share a SIMD with a wave of
+  // a throughput launch (the chunks of nu = L*Z on the second stream): issue first
+  __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bi = blockIdx.x / nbn, bj = blockIdx.x % nbn, z = blockIdx.y;
   const double *__restrict__ A = g.A + g.strideA * z;
