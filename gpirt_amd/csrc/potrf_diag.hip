@@ -10,6 +10,13 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int XLD = TILE + 2;   // row stride of the LDS image (even: pairs stay 16-byte aligned)
 constexpr int SB = 32;          // inner block size
 
+#ifdef DIAG_STAMPS
+__device__ long long g_diag_stamps[32];
+#define STAMP(i) do { if (threadIdx.x == 0) g_diag_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ v4d mfma4(double a, double b, v4d c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
   const int lr = lane & 15, lk = lane >> 4;
   double *A = S + (int64_t)n_pad * n_pad * z + (int64_t)kb * TILE * (n_pad + 1);
   double *Inv = inv_diag + inv_group_elems(n_pad) * z + inv_block_offset(kb);   // ld = SUP
+  STAMP(0);
 
   // block in: 16 independent 16-byte loads per thread are issued before the first is used
   {
@@ -118,6 +126,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
     }
   }
   __syncthreads();
+  STAMP(1);
 
   for (int p = 0; p < TILE / SB; ++p) {
     const int i0 = p * SB;
@@ -148,6 +157,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
       }
     }
     __syncthreads();
+    STAMP(2 + 3 * p);
 
     const int R = TILE - i0 - SB;                  // rows below the diagonal block
     const int NT = R / 16;
@@ -171,6 +181,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
       }
     }
     __syncthreads();
+    STAMP(3 + 3 * p);
     // trailing update on the lower 16x16 tiles: A_ij -= L_ip L_jp^T
     for (int e = wave; e < NT * (NT + 1) / 2; e += 4) {
       int ti = 0;
@@ -187,6 +198,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
       for (int g = 0; g < 4; ++g) T[(ri + lk + 4 * g) * XLD + rj + lr] -= acc[g];
     }
     __syncthreads();
+    STAMP(4 + 3 * p);
   }
 
   // the diagonal tiles of the trailing update also wrote their upper halves: L's strict upper
@@ -202,6 +214,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
     }
   }
   __syncthreads();
+  STAMP(14);
 
   // Off-diagonal blocks of X = L^-1 by recursive doubling: for a lower-triangular
   // [[A,0],[B,C]] the inverse is [[A^-1,0],[-C^-1 B A^-1, C^-1]].  Level 1 fills X_10 and
@@ -245,6 +258,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
       }
     }
     __syncthreads();
+    STAMP(15);
     // ---- level 2, inner product M = L_BA X_AA: wave = 16-row tile of the lower 64 rows -----
     {
       const int ti = wave;
@@ -265,6 +279,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
         for (int g = 0; g < 4; ++g) T[(16 * cs + lr) * XLD + 64 + 16 * ti + lk + 4 * g] = acc[cs][g];
     }
     __syncthreads();
+    STAMP(16);
     // ---- level 2, X_BA = -X_BB M: wave = column strip of 16 (reads and writes only its own
     // 16 image rows of the parked M) ----------------------------------------------------------
     {
@@ -288,16 +303,20 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
     }
     __syncthreads();
   }
+  STAMP(17);
 
   {
     const int i2 = (tid & 63) * 2, cq = tid >> 6;
 #pragma unroll 8
     for (int s2 = 0; s2 < 32; ++s2) {
       const int c = cq + 4 * s2;
-      *reinterpret_cast<double2 *>(Inv + i2 + SUP * c) =
-          make_double2(x_at(T, dinv, i2, c), x_at(T, dinv, i2 + 1, c));
+      // the inverse image's strict upper triangle is zero from its allocation on and stays so
+      if (c <= i2 + 1)
+        *reinterpret_cast<double2 *>(Inv + i2 + SUP * c) =
+            make_double2(x_sel(T, dinv, i2, c), x_sel(T, dinv, i2 + 1, c));
     }
   }
+  STAMP(18);
 }
 
 int launch_potrf_diag(hipStream_t st, double *S, int n_pad, int kb, int batch, double *inv_diag, int nb,
