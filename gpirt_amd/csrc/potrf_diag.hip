@@ -92,6 +92,32 @@ __device__ __forceinline__ void blk_range(double (&x)[SB], double (&uc)[SB], dou
   }
 }
 
+// tile e of the lower 16x16 tiles (row-major over the triangle) of the trailing update of the
+// step whose diagonal block starts at j0: A_ij -= L_ip L_jp^T
+__device__ __forceinline__ void trailing_tile(double *T, int j0, int e, int lr, int lk) {
+  int ti = 0;
+  while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
+  const int tj = e - ti * (ti + 1) / 2;
+  const int ri = j0 + SB + 16 * ti, rj = j0 + SB + 16 * tj;
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < SB / 4; ++kk) {
+    const int k = j0 + 4 * kk + lk;
+    acc = mfma4(T[(ri + lr) * XLD + k], T[(rj + lr) * XLD + k], acc);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) T[(ri + lk + 4 * g) * XLD + rj + lr] -= acc[g];
+}
+
+// columns c0 + wq, c0 + wq + nwq, ... (< c0 + 32) of L back to global: two rows per lane
+__device__ __forceinline__ void store_l_columns(const double *T, double *A, int n_pad, int c0, int wq, int nwq,
+                                                int lane) {
+  const int i2 = lane * 2;
+  for (int c = c0 + wq; c < c0 + SB; c += nwq)
+    *reinterpret_cast<double2 *>(A + i2 + (int64_t)n_pad * c) =
+        make_double2(i2 >= c ? T[i2 * XLD + c] : 0.0, i2 + 1 >= c ? T[(i2 + 1) * XLD + c] : 0.0);
+}
+
 // One workgroup (4 waves) factors a 128x128 block in LDS and inverts the factor, blocked by
 // 32: wave 0 factors and inverts the 32x32 diagonal block in registers, then all four waves
 // apply the panel solve and the trailing update with FP64 MFMA straight from LDS.  The
@@ -155,6 +181,13 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
         const int own = ((int)(c > r) ^ half) ^ 1;            // low half: c <= r, high half: c > r
         Trow[own ? i0 + c : TILE + half] = x[c];
       }
+    } else if (p > 0) {
+      // beside the factorisation of block p, on the other three SIMDs: what is left of step p-1
+      // (its three tiles that make up block p were waited for) and the store of column block
+      // p-1, which is final.  None of it touches block p or reads what wave 0 writes.
+      const int j0 = i0 - SB, NTq = (TILE - j0 - SB) / 16;
+      for (int e = 3 + (wave - 1); e < NTq * (NTq + 1) / 2; e += 3) trailing_tile(T, j0, e, lr, lk);
+      store_l_columns(T, A, n_pad, j0, wave - 1, 3, lane);
     }
     __syncthreads();
     STAMP(2 + 3 * p);
@@ -182,37 +215,17 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
     }
     __syncthreads();
     STAMP(3 + 3 * p);
-    // trailing update on the lower 16x16 tiles: A_ij -= L_ip L_jp^T
-    for (int e = wave; e < NT * (NT + 1) / 2; e += 4) {
-      int ti = 0;
-      while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
-      const int tj = e - ti * (ti + 1) / 2;
-      const int ri = i0 + SB + 16 * ti, rj = i0 + SB + 16 * tj;
-      v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < SB / 4; ++kk) {
-        const int k = i0 + 4 * kk + lk;
-        acc = mfma4(T[(ri + lr) * XLD + k], T[(rj + lr) * XLD + k], acc);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) T[(ri + lk + 4 * g) * XLD + rj + lr] -= acc[g];
-    }
+    // the three tiles of the trailing update that make up the next diagonal block; the other
+    // tiles run beside that block's factorisation
+    if (NT >= 2 && wave < 3) trailing_tile(T, i0, wave, lr, lk);
     __syncthreads();
     STAMP(4 + 3 * p);
   }
 
   // the diagonal tiles of the trailing update also wrote their upper halves: L's strict upper
   // triangle inside each 32-block was re-zeroed by the factor step, the rest of the upper
-  // triangle is where X goes next.  L back to global first.
-  {
-    const int i2 = (tid & 63) * 2, cq = tid >> 6;
-#pragma unroll 8
-    for (int s2 = 0; s2 < 32; ++s2) {
-      const int c = cq + 4 * s2;
-      *reinterpret_cast<double2 *>(A + i2 + (int64_t)n_pad * c) =
-          make_double2(i2 >= c ? T[i2 * XLD + c] : 0.0, i2 + 1 >= c ? T[(i2 + 1) * XLD + c] : 0.0);
-    }
-  }
+  // triangle is where X goes next.  The last column block of L back to global first.
+  store_l_columns(T, A, n_pad, TILE - SB, wave, 4, lane);
   __syncthreads();
   STAMP(14);
 
