@@ -162,6 +162,19 @@ def _pair(cfg, y, **kw):
     return Sampler(cfg, y, **kw), oracle.Sampler(cfg, y, **kw)
 
 
+def assert_states_agree(sg, sc, tag=None):
+    """theta, beta and the thresholds are rotations of exactly shared draws once every accept /
+    shrink decision coincides: they must agree to rounding (1e-9).  f and f* go through solves
+    with K + 1e-6 I (condition ~1e9-1e10), which bounds their agreement at 1e-5."""
+    for k in ("theta", "beta"):
+        assert np.abs(sg[k] - sc[k]).max() < 1e-9, (tag, k)
+    fin = np.isfinite(sc["threshold"])
+    assert np.array_equal(fin, np.isfinite(sg["threshold"])), tag
+    assert np.abs(sg["threshold"][fin] - sc["threshold"][fin]).max() < 1e-9, (tag, "threshold")
+    for k in ("f", "fstar"):
+        assert np.abs(sg[k] - sc[k]).max() < 1e-5, (tag, k)
+
+
 @pytest.mark.parametrize("stem,C,const,flags", [("2PL_C_2", 2, 0, 0), ("Wiener_C_5", 5, 0, 0),
                                                  ("2PL_C_5", 5, 1, 0),
                                                  ("Wiener_C_5", 5, 0, _abi.EXACT_FSTAR),
@@ -174,9 +187,8 @@ def _pair(cfg, y, **kw):
                                                  ("2PL_C_5", 5, 1, _abi.THETA_TABLE)])
 def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const, flags):
     """Three whole sweeps from the same state with the shared generator: every accept /
-    shrink decision must coincide, so the states agree to rounding.  Tolerance 1e-5: f* goes
-    through solves with K + 1e-6 I (condition ~1e9), which bounds agreement of anything
-    downstream of it."""
+    shrink decision must coincide, so the states agree to rounding (theta, beta, thresholds:
+    1e-9; f and f*, which go through solves with K + 1e-6 I of condition ~1e9: 1e-5)."""
     d = load_fixture(stem)
     y = d["y"][:, :, :4] if const else d["y"]
     theta = d["theta"][:, :y.shape[2]]
@@ -186,12 +198,7 @@ def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const, flags):
     g, c = _pair(cfg, y, theta_init=theta)
     for sweep in range(3):
         g.sweep(1); c.sweep(1)
-        sg, sc = g.state(), c.state()
-        for k in ("theta", "beta", "f", "fstar"):
-            assert np.abs(sg[k] - sc[k]).max() < 1e-5, (sweep, k)
-        fin = np.isfinite(sc["threshold"])
-        assert np.array_equal(fin, np.isfinite(sg["threshold"]))
-        assert np.abs(sg["threshold"][fin] - sc["threshold"][fin]).max() < 1e-5
+        assert_states_agree(g.state(), c.state(), sweep)
     dg, dc = g.diagnostics(), c.diagnostics()
     assert dg == dc
     g.close(); c.close()
@@ -216,11 +223,7 @@ def test_sweep_matches_oracle_wide_units(n, m, sweeps, flags):
     g, c = _pair(cfg, d["y"], theta_init=d["theta"])
     for sweep in range(sweeps):
         g.sweep(1); c.sweep(1)
-        sg, sc = g.state(), c.state()
-        for k in ("theta", "beta", "f", "fstar"):
-            assert np.abs(sg[k] - sc[k]).max() < 1e-5, (sweep, k)
-        fin = np.isfinite(sc["threshold"])
-        assert np.abs(sg["threshold"][fin] - sc["threshold"][fin]).max() < 1e-5
+        assert_states_agree(g.state(), c.state(), sweep)
     assert g.diagnostics() == c.diagnostics()
     g.close(); c.close()
 
@@ -237,9 +240,7 @@ def test_sweep_matches_oracle_many_items(flags):
     g, c = _pair(cfg, d["y"], theta_init=d["theta"])
     for sweep in range(2):
         g.sweep(1); c.sweep(1)
-        sg, sc = g.state(), c.state()
-        for k in ("theta", "beta", "f", "fstar"):
-            assert np.abs(sg[k] - sc[k]).max() < 1e-5, (sweep, k)
+        assert_states_agree(g.state(), c.state(), sweep)
     assert g.diagnostics() == c.diagnostics()
     g.close(); c.close()
 
@@ -386,9 +387,7 @@ def test_inputs_outside_the_node_range_take_the_dense_routes(flags):
     g, c = _pair(cfg, d["y"], theta_init=theta)
     for sweep in range(3):
         g.sweep(1); c.sweep(1)
-        sg, sc = g.state(), c.state()
-        for k in ("theta", "beta", "f", "fstar"):
-            assert np.abs(sg[k] - sc[k]).max() < 1e-5, (sweep, k)
+        assert_states_agree(g.state(), c.state(), sweep)
     assert g.diagnostics() == c.diagnostics()
     g.close(); c.close()
 
@@ -403,10 +402,45 @@ def test_short_length_scale_falls_back_to_the_dense_routes(flags):
     g, c = _pair(cfg, d["y"], theta_init=d["theta"])
     for sweep in range(2):
         g.sweep(1); c.sweep(1)
-        sg, sc = g.state(), c.state()
-        for k in ("theta", "beta", "f", "fstar"):
-            assert np.abs(sg[k] - sc[k]).max() < 1e-5, (sweep, k)
+        assert_states_agree(g.state(), c.state(), sweep)
     g.close(); c.close()
+
+
+@pytest.mark.parametrize("flags", [_abi.FSTAR_SOLVE, 0])
+def test_256_nodes_with_fewer_inputs_than_nodes(flags):
+    """irf_ls = 0.4 needs 256 Chebyshev nodes for the cross-covariance; with n = 100 inputs
+    (padded to 128) the [units x nodes] image of the f* step is wider than the unit columns it
+    is parked in are long.  FSTAR_SOLVE goes through that image on every sweep, the default
+    route whenever a theta leaves the grid's range."""
+    from gpirt_amd.synth import generate
+    d = generate(100, 9, 3, seed=21)
+    theta = d["theta"].copy()
+    if not flags:
+        theta[5, 0] = 5.4
+    cfg = _abi.default_config(n=100, m=9, H=1, C=3, seed=7, irf_ls=0.4, flags=flags)
+    g, c = _pair(cfg, d["y"], theta_init=theta)
+    for sweep in range(3):
+        g.sweep(1); c.sweep(1)
+        assert_states_agree(g.state(), c.state(), sweep)
+    assert g.diagnostics() == c.diagnostics()
+    g.close(); c.close()
+
+
+def test_clustered_theta_escalates_the_jitter_on_both_prior_routes():
+    """Near-duplicate inputs with a jitter far below rounding level: the factorisation fails, the
+    dense route retries with ten times the jitter and counts it (as the oracle does), and the
+    generator form of the factor hands such a sweep to the dense route instead of giving up."""
+    from gpirt_amd.synth import generate
+    d = generate(300, 6, 3, seed=5)
+    theta = np.repeat(d["theta"][::10], 10, axis=0) + 1e-9 * np.arange(300)[:, None]
+    for flags in (0, _abi.GENERATOR_PRIOR):
+        cfg = _abi.default_config(n=300, m=6, H=1, C=3, seed=3, jitter=1e-17, flags=flags)
+        g, c = _pair(cfg, d["y"], theta_init=theta)
+        g.sweep(1); c.sweep(1)
+        dg, dc = g.diagnostics(), c.diagnostics()
+        assert dg["jitter_retries"] >= 1 and dc["jitter_retries"] >= 1
+        assert np.isfinite(g.state()["theta"]).all()
+        g.close(); c.close()
 
 
 def test_gpirtmcmc_passes_flags_through():
