@@ -123,6 +123,7 @@ struct gpirt_sampler {
   int gen_now;               // this sweep's factor is in generator form
   int super_inv_ready;       // the off-diagonal blocks of this sweep's inverted super-blocks are built
   int theta_inside;          // this sweep's inputs all lie inside the nodes' range
+  int h_info2;               // host copy of the status of this sweep's low-rank f* factorisation
   int fs_nodes, fs_rank;     // nodes in use and their padded count (0: exact cross-covariance)
   int summary_draws;
   int32_t *d_done, *d_info, *d_remaining;
@@ -499,7 +500,8 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   A_(s->d_theta, (size_t)n * H);
   A_(s->d_f, (size_t)Np_pad * U_pad);
   A_(s->d_Z, (size_t)Np_pad * U_pad);
-  A_(s->d_nu, (size_t)Np_pad * U_pad);
+  // nu doubles as the [U_pad, R] image of F^T S^-1 K(x, c) in the f* step (R <= 2 TILE nodes)
+  A_(s->d_nu, (size_t)max(Np_pad, 2 * TILE) * U_pad);
   A_(s->d_S, (size_t)Np_pad * Np_pad * P);
   A_(s->d_inv, (size_t)inv_group_elems(Np_pad) * P);
   A_(s->d_fwork, (size_t)potrf_work_elems(Np_pad, P));
@@ -758,10 +760,9 @@ static int phase_factor_generator(gpirt_sampler *s, int *done) {
   int info = 0;
   GP_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, s->st));
   GP_HIP(hipStreamSynchronize(s->st));
-  if (info) {
-    set_error("generator form of the prior factor: a block is not positive definite (pivot %d)", info);
-    return GPIRT_ERR_NOT_PD;
-  }
+  // a block that is not positive definite: this sweep takes the dense route, which escalates
+  // the jitter and counts the retries
+  if (info) return GPIRT_OK;
   *done = 1;
   return GPIRT_OK;
 }
@@ -1123,6 +1124,16 @@ static int phase_fstar(gpirt_sampler *s) {
   return GPIRT_OK;
 }
 
+// The 128 x 128 factorisation of the low-rank f* step reports through d_info[2]; h_info2 is the
+// host copy taken behind this sweep's f* step.  A failure ends the sweep that consumed the f*.
+static int fstar_status(gpirt_sampler *s) {
+  if (!s->h_info2) return GPIRT_OK;
+  set_error("low-rank f* step: s2 I + Phi^T Phi is not positive definite (pivot %d)", s->h_info2);
+  s->h_info2 = 0;
+  (void)hipMemsetAsync(s->d_info + 2, 0, sizeof(int), s->st);
+  return GPIRT_ERR_NOT_PD;
+}
+
 static ThetaArgs theta_args(gpirt_sampler *s) {
   ThetaArgs a{};
   a.theta = s->d_theta; a.xc = s->d_xc; a.nu = s->d_tnu; a.prop = s->d_prop; a.hh = s->d_hh;
@@ -1199,7 +1210,9 @@ static int phase_theta(gpirt_sampler *s) {
                           hipMemcpyDeviceToHost, s->st));
     GP_HIP(hipMemcpyAsync(hist.data() + R + 3, s->d_remaining + R + 3, sizeof(int), hipMemcpyDeviceToHost,
                           s->st));
+    if (s->fs_lowrank) GP_HIP(hipMemcpyAsync(&s->h_info2, s->d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s->st));
     GP_HIP(hipStreamSynchronize(s->st));
+    GP_TRY(fstar_status(s));
     for (int q = r; q <= last; ++q) {
       active = hist[q];
       if (!active) { finished = true; break; }    // rounds after q (if any) found nobody active
@@ -1255,8 +1268,13 @@ int gpirt_sampler_sweep(gpirt_sampler *s, int32_t sweeps) {
       GP_TRY(collect_times(s));
     }
   }
+  // the last sweep's f* status would otherwise be seen by the next call only (grid-mode
+  // respondent steps never look at it inside the sweep)
+  if (s->fs_lowrank && sweeps > 0)
+    GP_HIP(hipMemcpyAsync(&s->h_info2, s->d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s->st));
   GP_HIP(hipStreamSynchronize(s->st));
   GP_TRY(collect_times(s));
+  GP_TRY(fstar_status(s));
   return GPIRT_OK;
 }
 
