@@ -39,6 +39,7 @@ SYMBOLS = {
     "gpirt_sampler_destroy": (None, [C.c_void_p]),
     "gpirt_k_build": (C.c_int, [_dp, C.c_int32, C.c_double, C.c_double, C.c_double, _dp]),
     "gpirt_potrf": (C.c_int, [_dp, C.c_int32, _dp]),
+    "gpirt_potrf_noalloc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "gpirt_trmm_lz": (C.c_int, [_dp, _dp, C.c_int32, C.c_int32, _dp]),
     "gpirt_potrs": (C.c_int, [_dp, _dp, C.c_int32, C.c_int32, _dp]),
     "gpirt_ordinal_loglik": (C.c_int, [_dp, _bp, _dp, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace gpirt {
@@ -1784,6 +1785,87 @@ int gpirt_fstar_predict(const double *x, const double *L, const double *f, int32
   GP_TRY(launch_export_fstar(0, dGt.as<double>(), up, n_grid, 1, u, up, dout.as<double>()));
   GP_HIP(hipMemcpy(fstar, dout.p, sizeof(double) * (size_t)n_grid * u, hipMemcpyDeviceToHost));
   GP_HIP(hipDeviceSynchronize());
+  return GPIRT_OK;
+}
+
+}  // extern "C"
+
+// ---- Cholesky without allocation ---------------------------------------------------------
+// gpirt_potrf's device work needs three buffers beyond the caller's matrix: the matrix padded to
+// tiles (pad block = identity), the inverted diagonal blocks the panel solves multiply by, and
+// the status word.  Here they live in one file-scope device array, so that the entry point below
+// never allocates.  In host code the array's name is only a handle for hipGetSymbolAddress: each
+// GPU holds its own copy at its own address, looked up once per device and kept in g_scratch_ptr.
+namespace {
+constexpr int kNoAllocMaxN = GPIRT_POTRF_NOALLOC_MAX_N;                       // 1024
+constexpr int64_t kScrS = (int64_t)kNoAllocMaxN * kNoAllocMaxN;               // padded matrix
+constexpr int64_t kScrInv = ((kNoAllocMaxN / TILE + 3) / 4) * (int64_t)SUP * SUP;  // inverted blocks
+constexpr int64_t kScrInfo = 32;                                              // status word (+ pad)
+constexpr int64_t kScrElems = kScrS + kScrInv + kScrInfo;
+constexpr int kMaxDevices = 64;
+}  // namespace
+static __device__ __align__(256) double scratch[kScrElems];
+static double *g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mutex;
+
+// the calling thread's current device's copy of `scratch`
+static int scratch_for_current_device(double **out) {
+  int dev = -1;
+  GP_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) { set_error("device index %d out of range", dev); return GPIRT_ERR_BAD_ARG; }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    double *p = nullptr;
+    GP_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+    if (!p) { set_error("hipGetSymbolAddress(scratch) returned a null address"); return GPIRT_ERR_HIP; }
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return GPIRT_OK;
+}
+
+// dst [np, np] <- src [n, n] (ld lds), zero pad rows / columns, identity on the pad block
+__global__ void pad_in_kernel(const double *__restrict__ src, int64_t lds, int n, double *__restrict__ dst, int np) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= np) return;
+  dst[i + (int64_t)np * j] = (i < n && j < n) ? src[i + lds * j] : (i == j ? 1.0 : 0.0);
+}
+// dst [n, n] (ld ldd) <- lower triangle of src [np, np], strict upper triangle zero
+__global__ void tril_out_kernel(const double *__restrict__ src, int np, int n, double *__restrict__ dst, int64_t ldd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= n) return;
+  dst[i + ldd * j] = i >= j ? src[i + (int64_t)np * j] : 0.0;
+}
+
+extern "C" {
+
+int gpirt_potrf_noalloc(const double *d_S, int64_t lds, int32_t n, double *d_L, int64_t ldl, void *stream) {
+  if (!d_S || !d_L || n < 1 || lds < n || ldl < n) { set_error("gpirt_potrf_noalloc: bad argument"); return GPIRT_ERR_BAD_ARG; }
+  if (n > kNoAllocMaxN) {
+    set_error("gpirt_potrf_noalloc: n = %d exceeds the static scratch's limit of %d rows (use gpirt_potrf, "
+              "which allocates)", n, kNoAllocMaxN);
+    return GPIRT_ERR_BAD_ARG;
+  }
+  GP_TRY(have_device());
+  double *base = nullptr;
+  GP_TRY(scratch_for_current_device(&base));
+  hipStream_t st = (hipStream_t)stream;
+  const int np = (int)pad_up(n);
+  double *S = base, *inv = base + kScrS;
+  int *info = reinterpret_cast<int *>(base + kScrS + kScrInv);
+  // the array keeps the last call's contents: the inverted blocks' upper halves are never
+  // written and must read zero, the status word must start clear, S is overwritten whole
+  GP_HIP(hipMemsetAsync(inv, 0, sizeof(double) * (size_t)inv_group_elems(np), st));
+  GP_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+  hipLaunchKernelGGL(pad_in_kernel, dim3((np + 255) / 256, np), dim3(256), 0, st, d_S, lds, n, S, np);
+  GP_HIP(hipGetLastError());
+  GP_TRY(launch_potrf(st, S, np, 1, inv, info, nullptr, nullptr, true));
+  hipLaunchKernelGGL(tril_out_kernel, dim3((n + 255) / 256, n), dim3(256), 0, st, S, np, n, d_L, ldl);
+  GP_HIP(hipGetLastError());
+  int h_info = 0;
+  GP_HIP(hipMemcpyAsync(&h_info, info, sizeof(int), hipMemcpyDeviceToHost, st));
+  GP_HIP(hipStreamSynchronize(st));
+  if (h_info) { set_error("gpirt_potrf_noalloc: pivot %d is not positive", h_info); return GPIRT_ERR_NOT_PD; }
   return GPIRT_OK;
 }
 

@@ -293,6 +293,20 @@ int gpirt_k_build(const double *x, int32_t n, double ls, double sf, double jitte
  * chol(K) idiom generate_data.R:56).  L[n,n], strict upper triangle zeroed.
  * Returns GPIRT_ERR_NOT_PD when a pivot is not positive. */
 int gpirt_potrf(const double *S, int32_t n, double *L);
+/* gpirt_potrf for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * DEVICE pointers in and out: d_S [n,n] column-major with leading dimension lds (both
+ * triangles are read as gpirt_potrf reads them), d_L [n,n] with leading dimension ldl receives
+ * the lower factor with a zero strict upper triangle (d_L may be d_S).  `stream` is a
+ * hipStream_t (NULL: the default stream); the call returns after the stream has drained, with
+ * GPIRT_ERR_NOT_PD when a pivot is not positive.  The padded matrix, the inverted diagonal
+ * blocks and the status word live in one static device array of 12.6 MB per GPU that the library
+ * holds until the process ends; n is limited to GPIRT_POTRF_NOALLOC_MAX_N and larger sizes are
+ * refused with GPIRT_ERR_BAD_ARG.  Every call on a GPU shares that GPU's array: calls that
+ * overlap on one GPU (two host threads, two streams) race and must be serialised by the caller. */
+#define GPIRT_POTRF_NOALLOC_MAX_N 1024
+int gpirt_potrf_noalloc(const double *d_S, int64_t lds, int32_t n, double *d_L, int64_t ldl,
+                        void *stream);
 /* N = L * Z for all columns at once (nu = prior'*randn, utils/elliptical_slice.m:64).
  * L[n,n] lower, Z[n,k] -> N[n,k]. */
 int gpirt_trmm_lz(const double *L, const double *Z, int32_t n, int32_t k, double *N);
