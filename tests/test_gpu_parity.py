@@ -443,6 +443,23 @@ def test_clustered_theta_escalates_the_jitter_on_both_prior_routes():
         g.close(); c.close()
 
 
+@pytest.mark.parametrize("n,m,H,const", [(1, 1, 1, 0), (5, 3, 2, 0), (100, 10, 10, 0), (129, 2, 1, 0),
+                                         (513, 3, 1, 0), (7, 2, 40, 1), (100, 4, 6, 1)])
+def test_create_and_one_sweep_at_ragged_sizes(n, m, H, const):
+    """Set-up buffers are sized from padded counts (128-row tiles, 512-row super-blocks, one
+    group per period): sizes below one tile, one past a tile and one past a super-block, with
+    one and several periods, must create, sweep once and agree with the oracle."""
+    rng = np.random.default_rng(n + m + H)
+    y = rng.integers(0, 4, size=(n, m, H)).astype(np.int8)          # C = 3, zeros = missing
+    theta = rng.normal(size=(n, H))
+    cfg = _abi.default_config(n=n, m=m, H=H, C=3, seed=9, theta_ls=max(H / 2, 1.0), constant_irf=const)
+    g, c = _pair(cfg, y, theta_init=theta)
+    g.sweep(1); c.sweep(1)
+    assert_states_agree(g.state(), c.state(), (n, m, H))
+    assert g.diagnostics() == c.diagnostics()
+    g.close(); c.close()
+
+
 def test_gpirtmcmc_passes_flags_through():
     """The mirror's `flags` reach gpirt_config: the generator form of the prior factor through
     gpirt_run gives the chain of the dense route (constant IRF: one group of 400 stacked inputs)."""
