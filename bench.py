@@ -179,8 +179,15 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    # the exchange of the sharded respondent step: by default the library's own RCCL collective
+    # (libgpirt_rccl.so, no torch on the data path; torch.distributed's gloo group only carries
+    # the communicator's 128-byte identifier, the barriers and the MAX of the ranks' clocks).
+    # GPIRT_BENCH_BACKEND=gloo rehearses the multi-rank logic on a box with fewer GPUs than
+    # ranks (exchange staged through host memory); GPIRT_BENCH_COLLECTIVE=torch selects the
+    # torch.distributed "nccl" hook instead.
     rehearsal = os.environ.get("GPIRT_BENCH_BACKEND") == "gloo"
-    if world > 1:
+    use_torch_nccl = world > 1 and not rehearsal and os.environ.get("GPIRT_BENCH_COLLECTIVE") == "torch"
+    if world > 1 and (rehearsal or use_torch_nccl):
         # torch first: it brings its own copy of the HIP runtime, and a process in which
         # libgpirt_hip.so has already initialised the system's copy finds no GPU from torch
         import torch
@@ -201,40 +208,25 @@ def main():
 
     dist = None
     hook = None
+    native = None
+    on_stream = False
+    torch_on_gpu = False
     if world > 1:
         import torch
         import torch.distributed as dist
         if rehearsal:
-            # rehearsal of the multi-rank logic on a box with fewer GPUs than ranks: gloo
-            # carries the exchange through host memory (not a performance configuration)
             dist.init_process_group(backend="gloo")
-            on_stream = False
             hook = torch_allreduce(device_buffers=True, via_host=True)
-        else:
+            torch_on_gpu = True
+        elif use_torch_nccl:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-            # stream-ordered hook: the collective is enqueued on the sampler's own HIP stream,
-            # no host round trip per proposal round (GPIRT_BENCH_SYNC_ALLREDUCE=1: blocking hook)
             on_stream = not os.environ.get("GPIRT_BENCH_SYNC_ALLREDUCE")
-            if on_stream:
-                # try the stream-ordered hook once on a stream of torch's own; every rank falls
-                # back to the blocking hook unless it worked everywhere
-                ok = 1.0
-                try:
-                    probe = torch_allreduce(device_buffers=True, on_stream=True)
-                    side = torch.cuda.Stream()
-                    probe.stream_ptr = side.cuda_stream
-                    ones = torch.ones(1024, dtype=torch.float64, device="cuda")
-                    torch.cuda.synchronize()
-                    probe(ones.data_ptr(), ones.numel())
-                    side.synchronize()
-                    ok = float(bool(torch.all(ones == float(world)).item()))
-                except Exception as exc:                      # noqa: BLE001
-                    print("rank %d: stream-ordered all-reduce unavailable (%s)" % (rank, exc), file=sys.stderr)
-                    ok = 0.0
-                flag = torch.tensor([ok], dtype=torch.float64, device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                on_stream = bool(flag.item() > 0.5)
             hook = torch_allreduce(device_buffers=True, on_stream=on_stream)
+            torch_on_gpu = True
+        else:
+            from gpirt_amd import comm as gcomm
+            dist.init_process_group(backend="gloo")
+            native = gcomm.Comm(gcomm.exchange_id(rank, world), rank, world)
 
     n, m, C = args.n, args.m, args.C
     data = generate(n, m, C, seed=args.seed)          # identical on every rank
@@ -246,20 +238,36 @@ def main():
     keep = None
     if world > 1:
         cfg.item_begin, cfg.item_end = item_range(m, rank, world)
-        keep = _abi.ALLREDUCE_FN(lambda ptr, count, user: hook(ptr, count))
-        cfg.allreduce = keep
-        if on_stream:
-            cfg.flags |= _abi.ALLREDUCE_ON_STREAM
+        if native is not None:
+            native.bind(cfg)              # rank, world, the RCCL hook, stream-ordered
+        else:
+            keep = _abi.ALLREDUCE_FN(lambda ptr, count, user: hook(ptr, count))
+            cfg.allreduce = keep
+            if on_stream:
+                cfg.flags |= _abi.ALLREDUCE_ON_STREAM
     s = Sampler(cfg, data["y"], theta_init=theta_init, beta_prior_means=np.zeros((3, m)),
                 beta_prior_sds=np.ones((3, m)))
     if hook is not None:
         hook.stream_ptr = s.stream()
+    if native is not None:
+        native.set_stream(s.stream())
 
     def barrier():
+        # sweep() drains the sampler's streams before it returns: nothing is in flight here
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
+            if torch_on_gpu:
+                import torch
+                torch.cuda.synchronize()
             dist.barrier()
+
+    def max_over_ranks(v):
+        if dist is None:
+            return v
+        import torch
+        t = torch.tensor([v], dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     # the sampler times its first five sweeps of the dense route to choose between computing the
     # first rows of nu = L*Z beside the factorisation or after it (same chain bit for bit):
@@ -283,12 +291,7 @@ def main():
     ph1 = s.phase_times()
     d1 = s.diagnostics()
     r0 = min(s.nu_rows_beside_factor(), n)
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device="cpu" if dist.get_backend() == "gloo" else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
 
     # The same sweep with the prior factor kept in generator form (GPIRT_GENERATOR_PRIOR): the
     # headline above is the dense formulation (n x n Cholesky, nu = L*Z as one triangular
@@ -302,6 +305,8 @@ def main():
         if hook is not None:
             hook._ext = None
             hook.stream_ptr = s.stream()
+        if native is not None:
+            native.set_stream(s.stream())
         s.sweep(args.warmup)
         v0 = s.phase_times()
         barrier()
@@ -310,12 +315,7 @@ def main():
         barrier()
         v_elapsed = time.perf_counter() - tv
         v1 = s.phase_times()
-        if dist is not None:
-            import torch
-            t = torch.tensor([v_elapsed], dtype=torch.float64,
-                             device="cpu" if dist.get_backend() == "gloo" else "cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            v_elapsed = float(t.item())
+        v_elapsed = max_over_ranks(v_elapsed)
         variant = {"flags": "GPIRT_GENERATOR_PRIOR", "value": args.steps / v_elapsed, "unit": "sweeps/s",
                    "ms_per_step": 1e3 * v_elapsed / args.steps,
                    "phases_ms": {k: (v1[k][0] - v0[k][0]) / args.steps for k in v1},
@@ -361,7 +361,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic ordinal GPIRT, n=%d respondents, m=%d items, C=%d, H=1, "
                                    "1001-point grid, thresholds and beta sampled" % (n, m, C),
-                       "items_per_gpu": mloc, "parallelism": "items sharded x%d" % world},
+                       "items_per_gpu": mloc, "parallelism": "items sharded x%d" % world,
+                       "collective": ("none" if world == 1 else "libgpirt_rccl.so: ncclAllGather + sum in rank order, "
+                                      "stream-ordered" if native is not None else
+                                      "gloo through host memory (rehearsal)" if rehearsal else "torch.distributed nccl")},
             "roofline": {
                 "kernel": nu_kernel,
                 "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
@@ -395,6 +398,8 @@ def main():
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     s.close()
+    if native is not None:
+        native.close()
     if dist is not None:
         dist.destroy_process_group()
 

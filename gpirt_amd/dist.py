@@ -23,6 +23,27 @@ class _DevVec:
             "strides": None}
 
 
+def gather_sum_allreduce(group=None):
+    """CPU mirror (gloo, host buffers) of the native hook of ``libgpirt_rccl.so``: all-gather
+    the ranks' vectors, then add them in rank order -- every rank performs the same additions
+    in the same order, so all ranks end with the same bits."""
+    import torch
+    import torch.distributed as dist
+
+    def hook(ptr, count):
+        arr = np.ctypeslib.as_array((C.c_double * count).from_address(ptr))
+        mine = torch.from_numpy(arr.copy())
+        parts = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, mine, group=group)
+        acc = parts[0].numpy().copy()
+        for p in parts[1:]:
+            acc += p.numpy()
+        arr[:] = acc
+        return 0
+
+    return hook
+
+
 def torch_allreduce(group=None, device_buffers=True, via_host=False, on_stream=False):
     """Return ``f(ptr, count) -> 0`` summing `count` doubles at `ptr` over the process group,
     in place.  `device_buffers=True`: `ptr` is HBM on the current device (HIP backend);

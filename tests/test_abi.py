@@ -29,6 +29,20 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(_lib.SYMBOLS) == decl
 
 
+def test_collective_library_exports_what_its_header_declares():
+    """include/gpirt_comm.h is served by libgpirt_rccl.so (RCCL, no torch)."""
+    from gpirt_amd import comm
+    text = open(os.path.join(ROOT, "include", "gpirt_comm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decl = sorted(set(re.findall(r"\b(gpirt_comm_[a-z_0-9]+)\s*\(", text)))
+    lib = C.CDLL(comm.SO_PATH)
+    assert len(decl) >= 8
+    for name in decl:
+        assert hasattr(lib, name), "libgpirt_rccl.so does not export %s" % name
+    assert sorted(comm.SYMBOLS) == decl
+    assert not any(n.startswith("gpirt_comm_") for n in _lib.SYMBOLS)     # the main library stays RCCL-free
+
+
 def test_struct_layout_matches_header_defaults():
     lib = _lib.lib()
     c = _abi.GpirtConfig()

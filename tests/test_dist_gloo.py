@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, constant_irf):
+def _worker(rank, world, port, out_dir, constant_irf, fixed_order=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,7 +35,8 @@ def _worker(rank, world, port, out_dir, constant_irf):
     y, theta = d["y"][:, :, :3], d["theta"][:, :3]
     n, m, H = y.shape
     j0, j1 = item_range(m, rank, world)
-    hook = torch_allreduce(device_buffers=False)
+    from gpirt_amd.dist import gather_sum_allreduce
+    hook = gather_sum_allreduce() if fixed_order else torch_allreduce(device_buffers=False)
     calls = []
 
     def counted(ptr, count):
@@ -90,6 +91,35 @@ def test_two_rank_item_sharding_matches_single_rank(tmp_path, constant_irf):
         # exactly one n-vector all-reduce per lock-step round
         assert len(p["calls"]) == int(p["rounds"]) and np.all(p["calls"] == n)
     assert np.array_equal(parts[0]["calls"], parts[1]["calls"])
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_gather_then_fixed_order_sum_gives_every_rank_the_same_chain(tmp_path, world):
+    """The exchange of the native RCCL hook (all-gather + sum in rank order), mirrored on gloo:
+    all ranks hold bit-identical theta, and it equals the single-rank chain's theta -- the
+    re-associated sums differ at rounding level only, which no accept / shrink comparison of
+    these sweeps notices."""
+    import torch.multiprocessing as mp
+    from gpirt_amd import _abi
+    from oracle import oracle
+    from conftest import load_fixture
+
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), 0, True), nprocs=world, join=True)
+    d = load_fixture("Wiener_C_5")
+    y, theta = d["y"][:, :, :3], d["theta"][:, :3]
+    n, m, H = y.shape
+    cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=11, theta_ls=1.5)
+    ref = oracle.Sampler(cfg, y, theta_init=theta)
+    ref.sweep(3)
+    full = ref.state()
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for p in parts:
+        j0, j1 = int(p["j0"]), int(p["j1"])
+        assert np.array_equal(p["theta"], parts[0]["theta"])          # same bits on every rank
+        assert np.array_equal(p["theta"], full["theta"])              # and the unsharded chain's
+        assert np.array_equal(p["beta"], full["beta"][:, j0:j1])
+        assert np.array_equal(p["f"], full["f"][:, j0:j1])
+    assert sum(int(p["j1"]) - int(p["j0"]) for p in parts) == m
 
 
 def test_item_range_partitions_evenly():

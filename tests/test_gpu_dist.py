@@ -173,3 +173,66 @@ def test_bench_runs_with_two_ranks_under_the_launcher(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
     assert out["config"]["items_per_gpu"] == 32
+
+
+def _native_worker(rank, world, port, out_dir):
+    """The library's own RCCL collective (libgpirt_rccl.so), no torch on the GPU: (1) the hook on
+    a raw device buffer, twice with different lengths (its staging grows); (2) one RCCL rank
+    plays rank 0 of 2 -- it owns the first half of the items -- and the stream-ordered native
+    hook must drive the chain to the same state as a blocking hook that adds nothing."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    from gpirt_amd import _abi, _lib, comm
+    from gpirt_amd.dist import item_range
+    from gpirt_amd.sampler import Sampler
+    from conftest import load_fixture
+    from test_zz_no_alloc import Hip
+
+    _lib.check(_lib.lib().gpirt_set_device(0))
+    hip = Hip()
+    c = comm.Comm(comm.unique_id(), 0, 1)
+    stream = C.c_void_p()
+    assert hip.rt.hipStreamCreate(C.byref(stream)) == 0
+    c.set_stream(stream.value)
+    ok = True
+    for count in (1000, 4000, 70):
+        x = np.arange(count, dtype=np.float64) * 0.5
+        d = hip.upload(x)
+        c.allreduce(d.value, count)
+        assert hip.rt.hipStreamSynchronize(stream) == 0
+        ok = ok and np.array_equal(hip.download(d, (count,)), x)      # one rank: the sum is the vector
+        hip.free(d)
+    ok = ok and c.calls() == 3
+
+    d = load_fixture("Wiener_C_5")
+    y, theta = d["y"][:, :, :3], d["theta"][:, :3]
+    n, m, H = y.shape
+    j0, j1 = item_range(m, 0, 2)
+    states = []
+    for native in (False, True):
+        cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=11, theta_ls=1.5, item_begin=j0, item_end=j1,
+                                  rank=0, world=2)
+        if native:
+            c.bind(cfg)
+            cfg.world = 2                       # the chain believes in a second rank that adds nothing
+        else:
+            cb = _abi.ALLREDUCE_FN(lambda ptr, count, user: 0)
+            cfg.allreduce = cb
+        s = Sampler(cfg, y, theta_init=theta)
+        if native:
+            c.set_stream(s.stream())
+        s.sweep(3)
+        states.append((s.state(), s.diagnostics()))
+        s.close()
+    ok = ok and states[0][1] == states[1][1] and all(
+        np.array_equal(states[0][0][k], states[1][0][k]) for k in ("theta", "f", "fstar", "beta"))
+    ok = ok and c.calls() > 3
+    c.close()
+    open(os.path.join(out_dir, "native.txt"), "w").write("ok" if ok else "bad")
+
+
+def test_native_rccl_collective_without_torch(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_native_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert open(os.path.join(str(tmp_path), "native.txt")).read() == "ok"

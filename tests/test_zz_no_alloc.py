@@ -25,6 +25,8 @@ class Hip:
         self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.rt.hipFree.argtypes = [C.c_void_p]
         self.rt.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.rt.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.rt.hipStreamSynchronize.argtypes = [C.c_void_p]
 
     def alloc(self, nbytes):
         p = C.c_void_p()
