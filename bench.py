@@ -68,24 +68,20 @@ def substeps(n, m, C, G, ms, evals, r0=0):
     return out
 
 
-def pmc_traffic(n, m, world, r0):
-    """HBM bytes per launch of the nu = L*Z kernel from the committed rocprofv3 PMC passes
-    (FETCH_SIZE doubled as the gfx950 correction asks, plus WRITE_SIZE); counters cannot be
-    read from inside this process, so the figure is the one recorded under profiles/ for the
-    same configuration, or None when the configuration differs."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_nu_gemm.json")
+def pmc_record():
+    """The committed rocprofv3 PMC passes (profiles/r02_pmc_kernels.json: FETCH_SIZE doubled as the
+    gfx950 correction asks, plus WRITE_SIZE, separate passes; counters cannot be read from inside
+    this process).  Valid for the benchmark's own configuration on one GPU only."""
     try:
-        rec = json.load(open(path))
+        return json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")))
     except OSError:
         return None
-    c = rec.get("config", {})
-    if (c.get("n"), c.get("m"), c.get("n_gpus")) != (n, m, world):
+
+
+def pmc_kernel(rec, label, n, m, world):
+    if rec is None or world != 1 or (rec.get("config", {}).get("n"), rec.get("config", {}).get("m")) != (n, m):
         return None
-    if c.get("first_row", 0) == r0:
-        return rec["hbm_bytes_per_launch"]
-    if r0 == 0 and "whole_product_in_one_launch" in rec:
-        return rec["whole_product_in_one_launch"]["hbm_bytes_per_launch"]
-    return None
+    return rec["kernels"].get(label)
 
 
 def cpu_baseline(args, n, m, G):
@@ -282,11 +278,14 @@ def main():
     pa = s.phase_times()
     s.sweep(1)
     pb = s.phase_times()
-    nu_alone_ms = pb["nu"][0] - pa["nu"][0] if s.nu_rows_beside_factor() == 0 else None
+    alone = s.nu_rows_beside_factor() == 0       # sweep 2 of the set-up runs nothing beside the factorisation
+    nu_alone_ms = pb["nu"][0] - pa["nu"][0] if alone else None
+    potrf_alone_ms = pb["potrf"][0] - pa["potrf"][0] if alone else None
     s.sweep(SETUP_SWEEPS - 2)
     s.sweep(args.warmup)
     ph0 = s.phase_times()
     d0 = s.diagnostics()
+    up0 = s.update_times()
     barrier()
     t0 = time.perf_counter()
     s.sweep(args.steps)                  # drains its stream before returning
@@ -294,6 +293,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ph1 = s.phase_times()
     d1 = s.diagnostics()
+    up1 = s.update_times()
     r0 = min(s.nu_rows_beside_factor(), n)
     elapsed = max_over_ranks(elapsed)
 
@@ -333,10 +333,13 @@ def main():
         launches = {k: (ph1[k][1] - ph0[k][1]) / args.steps for k in ph1}
         mloc = (cfg.item_end - cfg.item_begin) if world > 1 else m
         fl = dense_flops(n, mloc, cfg.n_grid)
-        # dominant kernel: the FP64 MFMA GEMM; its single largest launch per sweep is
-        # nu = L*Z (phase "nu" is exactly that launch, timed by HIP events on the sampler's own
-        # stream; with few column tiles per GPU -- sharded items -- the launch runs K in slabs
-        # and the phase includes the small kernel that adds them)
+        # Dominant kernel by device time: the FP64 MFMA GEMM.  Two of its instances carry the dense
+        # work of a sweep: the rank-512 trailing updates of the Cholesky (gemm_f64_kernel<false,true,1>,
+        # ~19 launches per sweep, each bracketed by HIP events on the sampler's stream during the
+        # timed region) and nu = L*Z (phase "nu": the one launch per sweep after the factorisation,
+        # timed the same way; the rows computed beside the factorisation run as chunks on a second
+        # stream and are inside the "potrf" span).
+        rec = pmc_record()
         nu_ms = phases["nu"]
         tiles = -(-n // 128) * -(-mloc // 128)
         nu_kernel = ("gemm_f64_kernel<false,false,5> (nu = L*Z, rows %d..%d: one launch per sweep after the "
@@ -346,7 +349,11 @@ def main():
                      "gemm_f64_kernel<false,false,2> (nu = L*Z, one launch per sweep%s)"
                      % (", K in %d slabs + sum_slabs_kernel" % (8 if tiles < 512 else 4) if tiles < 1024 else ""))
         fl_launch = (float(n) * n - float(r0) * r0) * mloc      # triangular count of the rows r0..n
-        achieved = fl_launch / (nu_ms * 1e-3) / 1e12 if nu_ms > 0 else 0.0
+        nu_achieved = fl_launch / (nu_ms * 1e-3) / 1e12 if nu_ms > 0 else 0.0
+        upd_ms, upd_n, upd_fl = up1[0] - up0[0], up1[1] - up0[1], up1[2] - up0[2]
+        upd_achieved = upd_fl / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+        upd_pmc = pmc_kernel(rec, "syrk", n, m, world)
+        nu_pmc = pmc_kernel(rec, "nu_rest" if r0 > 0 else "nu_whole", n, m, world)
         evals = {k: (d1[k] - d0[k]) / args.steps for k in ("ess_f_rounds", "ess_param_rounds", "ess_theta_rounds")}
         dense_ms = phases["potrf"] + phases["nu"]     # the f* step no longer runs its algorithmic count
         out = {
@@ -370,11 +377,28 @@ def main():
                                       "stream-ordered" if native is not None else
                                       "gloo through host memory (rehearsal)" if rehearsal else "torch.distributed nccl")},
             "roofline": {
-                "kernel": nu_kernel,
-                "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "flop_per_launch": fl_launch, "ms_per_launch": nu_ms,
-                "traffic": pmc_traffic(n, m, world, r0),
+                "kernel": "gemm_f64_kernel<false,true,1> (rank-512 trailing updates of the blocked Cholesky, lower "
+                          "tiles only): the kernel with the largest share of device time",
+                "bound": "mfma", "achieved": upd_achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": upd_achieved / FP64_MFMA_PEAK_TFLOPS,
+                "launches_per_step": upd_n / args.steps if args.steps else 0,
+                "flop_per_launch": upd_fl / upd_n if upd_n else 0.0,
+                "ms_per_launch": upd_ms / upd_n if upd_n else 0.0,
+                "ms_per_step": upd_ms / args.steps if args.steps else 0.0,
+                "algorithmic_bytes_per_launch": ((upd_fl / upd_n) / (2.0 * 128 * 128 * 512) * (2 * 128 * 128 * 8)
+                                                 if upd_n else 0.0),
+                "traffic": upd_pmc["hbm_bytes_per_launch"] if upd_pmc else None,
+                "traffic_note": "mean HBM bytes per launch of this kernel from profiles/r02_pmc_kernels.json "
+                                "(rocprofv3 --pmc, 2 x FETCH_SIZE + WRITE_SIZE); algorithmic = read + write of "
+                                "each lower tile of the trailing matrix once (the 512-wide panel is re-read from cache)",
+                "other_instances": {
+                    "nu_after_factorisation": {
+                        "kernel": nu_kernel, "achieved": nu_achieved, "frac": nu_achieved / FP64_MFMA_PEAK_TFLOPS,
+                        "flop_per_launch": fl_launch, "ms_per_launch": nu_ms,
+                        "algorithmic_bytes_per_launch": 8.0 * ((float(n) * n - float(r0) * r0) / 2 + float(n) * mloc
+                                                               + float(n - r0) * mloc),
+                        "traffic": nu_pmc["hbm_bytes_per_launch"] if nu_pmc else None},
+                },
             },
             "substeps": substeps(n, mloc, C, cfg.n_grid, phases, evals, r0),
             "phases_ms": phases,
@@ -383,18 +407,35 @@ def main():
             "likelihood_evals_per_step": evals,
             "diagnostics": d1,
         }
-        if r0 > 0:
-            out["roofline"]["note"] = (
-                "rows %d..%d of nu = L*Z are what is left after the factorisation: at most 512 tiles, one "
-                "round of workgroups with the longest K, while the chunks of earlier rows that lag behind "
-                "the factorisation finish beside it on the second stream" % (r0, n))
-            if nu_alone_ms:
-                whole = float(n) * n * mloc / (nu_alone_ms * 1e-3) / 1e12
-                out["roofline"]["whole_product_in_one_launch"] = {
-                    "kernel": "gemm_f64_kernel<false,false,4>, sweep 2 of the set-up (no rows beside the factorisation)",
-                    "ms_per_launch": nu_alone_ms, "flop_per_launch": float(n) * n * mloc,
-                    "achieved": whole, "frac": whole / FP64_MFMA_PEAK_TFLOPS,
-                    "traffic": pmc_traffic(n, m, world, 0)}
+        if nu_alone_ms:
+            whole = float(n) * n * mloc / (nu_alone_ms * 1e-3) / 1e12
+            wp = pmc_kernel(rec, "nu_whole", n, m, world)
+            out["roofline"]["other_instances"]["nu_whole_product_in_one_launch"] = {
+                "kernel": "gemm_f64_kernel<false,false,4>, sweep 2 of the set-up (nothing beside the factorisation)",
+                "ms_per_launch": nu_alone_ms, "flop_per_launch": float(n) * n * mloc,
+                "achieved": whole, "frac": whole / FP64_MFMA_PEAK_TFLOPS,
+                "algorithmic_bytes_per_launch": 8.0 * (float(n) * n / 2 + 2.0 * n * mloc),
+                "traffic": wp["hbm_bytes_per_launch"] if wp else None}
+        if potrf_alone_ms:
+            ch = n ** 3 / 3.0 / (potrf_alone_ms * 1e-3) / 1e12
+            out["roofline"]["cholesky_phase_alone"] = {
+                "what": "the whole factorisation with nothing beside it (sweep 2 of the set-up): diagonal-block "
+                        "kernels, panel solves, in-panel updates and trailing updates, n^3/3 flop over its span",
+                "ms": potrf_alone_ms, "achieved": ch, "frac": ch / FP64_MFMA_PEAK_TFLOPS}
+        lik = {}
+        for label in ("ess_f", "ess_param", "theta_eval_bucket", "theta_table"):
+            k = pmc_kernel(rec, label, n, m, world)
+            if k:
+                lik[label] = {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"],
+                              "hbm_GBps_under_the_profiler": k["hbm_GBps_profiled"],
+                              "frac_of_hbm_peak": k["hbm_GBps_profiled"] / HBM_PEAK_GBS,
+                              "valu_insts_per_launch": k.get("SQ_INSTS_VALU"),
+                              "valu_issue_cycles_share_of_wave_cycles": k.get("valu_active_share_of_wave_cycles")}
+        if lik:
+            out["likelihood_kernels_measured"] = {
+                "source": "profiles/r02_pmc_kernels.json (rocprofv3 --pmc passes of this benchmark; durations and "
+                          "rates are those under the profiler, which serialises kernels and lowers the clock)",
+                "bound": "FP64 VALU issue, not HBM: see valu_issue_cycles_share", "kernels": lik}
         if variant is not None:
             out["variants"] = {"generator_prior": variant}
         if world == 1 and not args.no_cpu_baseline:

@@ -27,6 +27,7 @@ SYMBOLS = {
     "gpirt_sampler_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "gpirt_sampler_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp]),
     "gpirt_sampler_phase_times": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_int64)]),
+    "gpirt_sampler_update_times": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_int64), _dp]),
     "gpirt_sampler_diagnostics": (C.c_int, [C.c_void_p, C.POINTER(_abi.GpirtOutputs)]),
     "gpirt_sampler_accumulate": (C.c_int, [C.c_void_p, C.c_int32]),
     "gpirt_sampler_summary": (C.c_int, [C.c_void_p, C.POINTER(_abi.GpirtSummary)]),

@@ -170,7 +170,13 @@ inline int64_t potrf_work_elems(int n_pad, int batch) {
 // `hook` (optional) is called on the host right after the launches that finish block columns
 // [o, oe) and the trailing update behind them have been enqueued: from then on (in stream order)
 // rows [o*TILE, oe*TILE) of L are final and the chain of small kernels of the next block columns begins.
-struct PotrfHook { int (*fn)(void *ctx, int o, int oe); void *ctx; };
+// `timer` (optional) is called right before (begin = 1) and right after (begin = 0) the launch of
+// each rank-512 trailing update, with that launch's algorithmic flop count: the caller may bracket
+// the launch with events of its own.
+struct PotrfHook {
+  int (*fn)(void *ctx, int o, int oe); void *ctx;
+  int (*timer)(void *ctx, int begin, double flop);
+};
 // With defer_super_inverses the off-diagonal blocks of the inverted super-blocks, which only the
 // triangular solves (launch_potrs) read, are left to a later launch_super_inverses call.
 int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, int *d_info,

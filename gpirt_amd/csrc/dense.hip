@@ -253,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs g, int nbn)
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bi = blockIdx.x / nbn, bj = blockIdx.x % nbn, z = blockIdx.y;
+  if (g.lower_only && bi < bj) return;   // C square: 64 x 64 tiles wholly above the diagonal are not wanted
   const double *__restrict__ A = g.A + g.strideA * z;
   const double *__restrict__ B = g.B + g.strideB * z;
   double *C = g.C + g.strideC * z;   // may alias A or B
@@ -334,6 +335,12 @@ static int launch_gemm_mode(hipStream_t st, const GemmArgs &a, int mode, dim3 gr
   return GPIRT_OK;
 }
 
+// lower-tiles-only launches with at most this many 128 x 128 tiles go to the 64 x 64 kernel
+static int small_lower_tiles() {
+  static const int v = getenv("GPIRT_SMALL_LOWER") ? atoi(getenv("GPIRT_SMALL_LOWER")) : 300;
+  return v;
+}
+
 int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
   if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return GPIRT_OK;
   if (a.M % TILE || a.N % TILE || a.K % BK || a.K <= 0) {
@@ -347,8 +354,14 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
     int64_t nsup = (int64_t)((nbm + 7) / 8) * ((nbn + 3) / 4);
     tiles = (nsup + 7) / 8 * 8 * 32;
   }
-  // few tiles and a depth that is a multiple of the chunk: the low-latency 64x64 variant
-  if (mode == 0 && tiles * a.batch <= SMALL_GEMM_TILES && a.K % SK == 0 && a.K <= 512) {
+  // few tiles and a depth that is a multiple of the chunk: the low-latency 64x64 variant.  The
+  // late trailing updates of the factorisation (lower tiles only, depth 512) have fewer tiles
+  // than the chip has workgroup slots: a 128 x 128 tile of that depth runs ~80 us however few
+  // there are, four 64 x 64 tiles side by side a third of that.
+  const int small_lower = small_lower_tiles();
+  if ((mode == 0 && tiles * a.batch <= SMALL_GEMM_TILES && a.K % SK == 0 && a.K <= 512) ||
+      (mode == 1 && !AT && BT && tiles * a.batch <= small_lower && a.K % SK == 0 && a.K <= 512)) {
+    if (mode == 1) tiles = (int64_t)nbm * nbn;      // the grid covers the square; tiles above the diagonal exit
     dim3 sgrid((unsigned)(4 * tiles), (unsigned)a.batch), block(256);
     if (!AT && BT) hipLaunchKernelGGL((gemm_small_kernel<false, true>), sgrid, block, 0, st, a, 2 * nbn);
     else if (!AT && !BT) hipLaunchKernelGGL((gemm_small_kernel<false, false>), sgrid, block, 0, st, a, 2 * nbn);
@@ -643,9 +656,15 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
       u.C = S + (int64_t)oe * TILE * (n_pad + 1); u.ldc = n_pad; u.strideC = sS;
       u.M = (nb - oe) * TILE; u.N = u.M; u.K = (oe - o) * TILE; u.batch = batch;
       u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
+      const double r = (double)(nb - oe);
+      const double flop = r * (r + 1.0) * 0.5 * 2.0 * TILE * TILE * (double)u.K * batch;   // lower tiles only
+      // timed: the launches of the 128 x 128-tile kernel (the last, small updates run on 64 x 64 tiles)
+      const bool timed = hook && hook->timer && r * (r + 1.0) * 0.5 * batch > small_lower_tiles();
+      if (timed) GP_TRY(hook->timer(hook->ctx, 1, flop));
       GP_TRY(launch_gemm(st, false, true, u));
+      if (timed) GP_TRY(hook->timer(hook->ctx, 0, flop));
     }
-    if (hook) GP_TRY(hook->fn(hook->ctx, o, oe));
+    if (hook && hook->fn) GP_TRY(hook->fn(hook->ctx, o, oe));
   }
   if (!defer_super_inverses) GP_TRY(launch_super_inverses(st, S, n_pad, batch, inv, work));
   return GPIRT_OK;

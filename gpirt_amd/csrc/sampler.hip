@@ -3,6 +3,8 @@
 // parity entry points that expose the same device kernels with injected inputs.
 #include "kernels.h"
 
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -21,6 +23,34 @@ void set_error(const char *fmt, ...) {
   vsnprintf(g_err, sizeof g_err, fmt, ap);
   va_end(ap);
 }
+
+// ---- roctx ranges ---------------------------------------------------------------------------
+// With GPIRT_ROCTX=1 every sub-step of a sweep is bracketed by a roctx range (k_build+potrf,
+// nu+ess_f, ess_param, fstar, theta, snap), so that a `rocprofv3 --marker-trace --kernel-trace`
+// run can be cut by sub-step.  The marker library is looked up at run time: nothing links
+// against it, and without the variable (or the library) the ranges cost one branch.
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char *e = getenv("GPIRT_ROCTX");
+    if (!e || !*e || *e == '0') return;
+    for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+      pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (push && pop) return;
+      push = nullptr; pop = nullptr;
+    }
+  }
+};
+static const Roctx &roctx() { static Roctx r; return r; }
+struct Range {
+  bool on;
+  explicit Range(const char *name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+  ~Range() { if (on) roctx().pop(); }
+};
 
 // ---- small RAII helpers for the entry points ---------------------------------------------
 struct DevBuf {
@@ -136,6 +166,11 @@ struct gpirt_sampler {
   std::vector<hipEvent_t> ev;
   size_t ev_used;
   std::vector<int> ev_phase;
+  // the factorisation's rank-512 trailing updates, timed one by one (event pairs around each launch)
+  std::vector<hipEvent_t> upd_ev;
+  size_t upd_used;
+  double upd_ms, upd_flop, upd_flop_pending;
+  int64_t upd_cnt;
   // nu = L Z beside the factorisation: the rows of the first nu_overlap super-panels (SUP rows
   // each) are computed on a second stream, in chunks of nu_chunk tile rows, once those rows of L
   // are final and the trailing update that followed them has drained -- beside the next
@@ -169,6 +204,7 @@ static void sampler_free(gpirt_sampler *s) {
                   s->d_Jb, s->d_jinv, s->d_Tb, s->d_Sbb, s->d_linv, s->d_Et, s->d_Wt, s->d_V};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : s->upd_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_panel) (void)hipEventDestroy(e);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->ev_z) (void)hipEventDestroy(s->ev_z);
@@ -690,6 +726,28 @@ static int collect_times(gpirt_sampler *s) {
     s->phase_cnt[ph] += 1;
   }
   s->ev_used = 0;
+  for (size_t i = 0; i + 1 < s->upd_used; i += 2) {
+    float ms = 0;
+    GP_HIP(hipEventElapsedTime(&ms, s->upd_ev[i], s->upd_ev[i + 1]));
+    s->upd_ms += ms;
+    s->upd_cnt += 1;
+  }
+  s->upd_flop += s->upd_flop_pending;
+  s->upd_flop_pending = 0.0;
+  s->upd_used = 0;
+  return GPIRT_OK;
+}
+
+// brackets one trailing update of the factorisation with a pair of events (see PotrfHook)
+static int update_timer(void *ctx, int begin, double flop) {
+  gpirt_sampler *s = (gpirt_sampler *)ctx;
+  if (s->upd_used == s->upd_ev.size()) {
+    hipEvent_t e;
+    GP_HIP(hipEventCreate(&e));
+    s->upd_ev.push_back(e);
+  }
+  GP_HIP(hipEventRecord(s->upd_ev[s->upd_used++], s->st));
+  if (!begin) s->upd_flop_pending += flop;
   return GPIRT_OK;
 }
 
@@ -826,6 +884,7 @@ static int fill_z(gpirt_sampler *s) {
 }
 
 static int phase_factor(gpirt_sampler *s) {
+  Range range("gpirt:factor (k_build + potrf)");
   s->gen_now = 0;
   s->z_filled = 0;
   s->nu_rows_done = 0;
@@ -843,7 +902,7 @@ static int phase_factor(gpirt_sampler *s) {
     s->span_kind[par] = s->dense_sweeps == 1 ? 0 : (s->dense_sweeps == 3 ? 1 : -1);
     s->span_open = par + 1;
   }
-  const PotrfHook hook{nu_panel_hook, s};
+  PotrfHook hook{nullptr, s, update_timer};
   for (;;) {
     s->nu_rows_done = 0;
     GP_TRY(mark(s, PH_KBUILD));
@@ -871,8 +930,8 @@ static int phase_factor(gpirt_sampler *s) {
       GP_TRY(launch_bary(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->d_nodes, s->d_bw, s->fs_nodes,
                          s->cfg.grid_lo, s->cfg.grid_lo + s->cfg.grid_step * (s->G - 1), s->d_W,
                          (int64_t)s->Np_pad * s->G_pad, s->d_info + 1));
-    GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info, s->d_fwork,
-                        s->ov_now ? &hook : nullptr, true));
+    hook.fn = s->ov_now ? nu_panel_hook : nullptr;
+    GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info, s->d_fwork, &hook, true));
     s->super_inv_ready = 0;
     GP_HIP(hipMemcpyAsync(info3, s->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, s->st));
     GP_HIP(hipStreamSynchronize(s->st));
@@ -899,6 +958,7 @@ static int phase_factor(gpirt_sampler *s) {
 static int fstar_lowrank_prefactor(gpirt_sampler *s, hipStream_t q);
 
 static int phase_f(gpirt_sampler *s) {
+  Range range("gpirt:f (nu = L Z + slice update)");
   if (!s->z_filled) GP_TRY(fill_z(s));
   else if (s->ov_now && !s->gen_now) GP_HIP(hipStreamWaitEvent(s->st, s->ev_z, 0));   // drawn on the second stream
   GP_TRY(mark(s, PH_NU));
@@ -970,6 +1030,7 @@ static int phase_f(gpirt_sampler *s) {
 }
 
 static int phase_param(gpirt_sampler *s) {
+  Range range("gpirt:param (beta + thresholds slice update)");
   GP_TRY(mark(s, PH_PARAM));
   EssParamArgs a{};
   a.f = s->d_f; a.ld = s->Np_pad; a.y = s->d_y; a.ldy = s->Np_pad; a.x = s->d_theta;
@@ -1024,6 +1085,7 @@ static int ensure_super_inverses(gpirt_sampler *s) {
 }
 
 static int phase_fstar(gpirt_sampler *s) {
+  Range range("gpirt:fstar");
   GP_TRY(mark(s, PH_FSTAR));
   // f*^T = F^T S^-1 K(x, xs)   (gp posterior mean, main.m:57-58).  The solve goes to whichever
   // side has fewer columns: W = S^-1 K(x,xs) (G columns, the same on every rank) or
@@ -1171,6 +1233,7 @@ static int exchange(gpirt_sampler *s, double *buf = nullptr, int64_t count = 0) 
 // gap), except with sharded items and a blocking hook, where every round passes through the
 // host for the exchange anyway.
 static int phase_theta(gpirt_sampler *s) {
+  Range range("gpirt:theta (respondent slice update)");
   GP_TRY(mark(s, PH_THETA));
   ThetaArgs a = theta_args(s);
   const int R = a.R;
@@ -1228,6 +1291,7 @@ static int phase_theta(gpirt_sampler *s) {
 
 // static respondent step (utils/sample_score.m:1-20): table, lp = T * onehot, draw
 static int phase_theta_grid(gpirt_sampler *s) {
+  Range range("gpirt:theta (grid inverse-CDF)");
   GP_TRY(mark(s, PH_THETA));
   ThetaArgs a = theta_args(s);
   GP_TRY(launch_grid_table(s->st, a, s->G_pad, s->d_T));
@@ -1244,6 +1308,7 @@ static int phase_theta_grid(gpirt_sampler *s) {
 }
 
 static int phase_snap(gpirt_sampler *s) {
+  Range range("gpirt:snap");
   GP_TRY(mark(s, PH_SNAP));
   GP_TRY(launch_snap(s->st, s->d_Gt, s->U_pad, s->d_theta, s->Np, s->Np, s->P, s->mloc, s->ML, s->G,
                      s->cfg.grid_lo, s->cfg.grid_step, s->d_f, s->Np_pad));
@@ -1256,6 +1321,7 @@ int gpirt_sampler_sweep(gpirt_sampler *s, int32_t sweeps) {
   if (!s) { set_error("sampler is NULL"); return GPIRT_ERR_BAD_ARG; }
   GP_HIP(hipSetDevice(s->device));
   for (int it = 0; it < sweeps; ++it) {
+    Range range("gpirt:sweep");
     GP_TRY(phase_factor(s));   // main.m:67 + the chol of sample_fs.m:2
     GP_TRY(phase_f(s));        // main.m:50-52
     GP_TRY(phase_param(s));
@@ -1264,7 +1330,7 @@ int gpirt_sampler_sweep(gpirt_sampler *s, int32_t sweeps) {
     GP_TRY(phase_snap(s));     // main.m:69-73
     GP_TRY(mark(s, -1));
     s->sweep++;
-    if (s->ev_used > 4096) {
+    if (s->ev_used > 4096 || s->upd_used > 4096) {
       GP_HIP(hipStreamSynchronize(s->st));
       GP_TRY(collect_times(s));
     }
@@ -1332,6 +1398,14 @@ int gpirt_sampler_phase_times(gpirt_sampler *s, double *ms, int64_t *count) {
     if (ms) ms[k] = s->phase_ms[k];
     if (count) count[k] = s->phase_cnt[k];
   }
+  return GPIRT_OK;
+}
+
+int gpirt_sampler_update_times(gpirt_sampler *s, double *ms, int64_t *launches, double *flop) {
+  if (!s) { set_error("sampler is NULL"); return GPIRT_ERR_BAD_ARG; }
+  if (ms) *ms = s->upd_ms;
+  if (launches) *launches = s->upd_cnt;
+  if (flop) *flop = s->upd_flop;
   return GPIRT_OK;
 }
 

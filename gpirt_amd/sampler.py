@@ -95,6 +95,12 @@ class Sampler:
         check(lib().gpirt_sampler_phase_times(self._h, _d(ms), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
         return {p: (float(ms[i]), int(cnt[i])) for i, p in enumerate(PHASES)}
 
+    def update_times(self):
+        """(ms, launches, flop) of the factorisation's rank-512 trailing updates since creation."""
+        ms, fl, cnt = C.c_double(), C.c_double(), C.c_int64()
+        check(lib().gpirt_sampler_update_times(self._h, C.byref(ms), C.byref(cnt), C.byref(fl)))
+        return float(ms.value), int(cnt.value), float(fl.value)
+
     def diagnostics(self):
         o = _abi.GpirtOutputs()
         check(lib().gpirt_sampler_diagnostics(self._h, C.byref(o)))

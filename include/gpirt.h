@@ -231,6 +231,11 @@ int gpirt_sampler_get_state(gpirt_sampler *s, double *theta, double *f, double *
  * 3 ess_f, 4 ess_param, 5 fstar solves+gemm, 6 theta step, 7 snap, 8 normal draws.
  * ms[9], count[9]. */
 int gpirt_sampler_phase_times(gpirt_sampler *s, double *ms, int64_t *count);
+/* The rank-512 trailing updates of the blocked Cholesky (the FP64 MFMA launches that carry most of
+ * its n^3/3 flop; the last few, with at most 300 tiles, run on another kernel and are left out), each
+ * bracketed by HIP events on the sampler's stream: device time summed over
+ * the launches since creation (ms), their number, and their algorithmic flop (lower tiles only). */
+int gpirt_sampler_update_times(gpirt_sampler *s, double *ms, int64_t *launches, double *flop);
 /* Diagnostics so far: fills the counters of `out` (buffers untouched). */
 int gpirt_sampler_diagnostics(gpirt_sampler *s, gpirt_outputs *out);
 /* ---- posterior summaries from running sums on the device ---------------------------
