@@ -24,6 +24,8 @@ FSTAR_SOLVE = 64
 GENERATOR_PRIOR = 128
 NO_NU_OVERLAP = 256
 
+SUMMARY_QUADRATIC, SUMMARY_SKIP_THETA, SUMMARY_DROP_FIRST_THETA = 1, 2, 4
+
 # stream tags of the counter-based generator (same values in both backends)
 TAG_F_Z, TAG_F_U, TAG_P_Z, TAG_P_U, TAG_T_Z, TAG_T_U, TAG_INIT = 1, 2, 3, 4, 5, 6, 7
 

@@ -156,7 +156,7 @@ struct gpirt_sampler {
   int theta_inside;          // this sweep's inputs all lie inside the nodes' range
   int h_info2;               // host copy of the status of this sweep's low-rank f* factorisation
   int fs_nodes, fs_rank;     // nodes in use and their padded count (0: exact cross-covariance)
-  int summary_draws;
+  int summary_draws, summary_theta_draws;
   int32_t *d_done, *d_info, *d_remaining;
   unsigned long long *d_counters;  // [3][2]: f, param, theta x (evaluations, capped)
   int64_t theta_rounds;
@@ -1519,7 +1519,8 @@ int gpirt_sampler_restore(gpirt_sampler *s, const void *blob, int64_t bytes) {
   return GPIRT_OK;
 }
 
-int gpirt_sampler_accumulate(gpirt_sampler *s, int32_t quadratic) {
+int gpirt_sampler_accumulate(gpirt_sampler *s, int32_t options) {
+  const int quadratic = options & GPIRT_SUMMARY_QUADRATIC;
   if (!s) { set_error("sampler is NULL"); return GPIRT_ERR_BAD_ARG; }
   GP_HIP(hipSetDevice(s->device));
   if (!s->d_sum_th) {
@@ -1528,7 +1529,10 @@ int gpirt_sampler_accumulate(gpirt_sampler *s, int32_t quadratic) {
     GP_TRY(dalloc(s->d_sum_p, (size_t)s->U_pad * s->C * s->G));
     GP_TRY(dalloc(s->d_sum_arg, (size_t)s->U_pad * s->G));
   }
-  GP_TRY(launch_summary_theta(s->st, s->d_theta, (int64_t)s->n * s->H, s->d_sum_th, s->d_sum_th2));
+  if (!(options & GPIRT_SUMMARY_SKIP_THETA)) {
+    GP_TRY(launch_summary_theta(s->st, s->d_theta, (int64_t)s->n * s->H, s->d_sum_th, s->d_sum_th2));
+    s->summary_theta_draws++;
+  }
   ThetaArgs a = theta_args(s);
   GP_TRY(launch_summary_prob(s->st, a, quadratic != 0, s->d_sum_p, s->d_sum_arg));
   GP_HIP(hipStreamSynchronize(s->st));
@@ -1543,11 +1547,13 @@ int gpirt_sampler_summary(gpirt_sampler *s, gpirt_summary *out) {
     return GPIRT_ERR_BAD_ARG;
   }
   GP_HIP(hipSetDevice(s->device));
-  const int K = s->summary_draws;
+  int K = s->summary_draws;
   out->draws = K;
   if (K < 1) { set_error("no draw has been accumulated"); return GPIRT_ERR_BAD_ARG; }
   const size_t nH = (size_t)s->n * s->H;
   if (out->theta_mean || out->theta_sd) {
+    K = s->summary_theta_draws;          // draws whose theta was accumulated
+    if (K < 1) { set_error("no draw's theta has been accumulated"); return GPIRT_ERR_BAD_ARG; }
     std::vector<double> a(nH), b(nH);
     GP_HIP(hipMemcpy(a.data(), s->d_sum_th, sizeof(double) * nH, hipMemcpyDeviceToHost));
     GP_HIP(hipMemcpy(b.data(), s->d_sum_th2, sizeof(double) * nH, hipMemcpyDeviceToHost));
@@ -1559,6 +1565,7 @@ int gpirt_sampler_summary(gpirt_sampler *s, gpirt_summary *out) {
         out->theta_sd[i] = K > 1 ? sqrt(var > 0.0 ? var : 0.0) : NAN;
       }
     }
+    K = s->summary_draws;
   }
   const int G = s->G, C = s->C, P = s->P, mloc = s->mloc, ML = s->ML, U_pad = s->U_pad;
   if (out->prob_mean) {
@@ -1623,7 +1630,7 @@ int gpirt_run(const gpirt_config *cfg, const int8_t *y, const double *theta_init
 int gpirt_run_summary(const gpirt_config *cfg, const int8_t *y, const double *theta_init,
                       const double *bpm, const double *bps, const double *tpm, const double *tps,
                       const double *thresholds, gpirt_outputs *out, gpirt_summary *summary,
-                      int32_t quadratic) {
+                      int32_t options) {
   gpirt_sampler *s = nullptr;
   GP_TRY(gpirt_sampler_create(cfg, y, theta_init, bpm, bps, tpm, tps, thresholds, &s));
   const int total = cfg->burn_iterations + cfg->sample_iterations;
@@ -1648,7 +1655,9 @@ int gpirt_run_summary(const gpirt_config *cfg, const int8_t *y, const double *th
           (out->fstar && (cfg->flags & GPIRT_RETURN_FSTAR)) ? out->fstar + sfs * k : nullptr,
           out->beta ? out->beta + sb * k : nullptr, out->threshold ? out->threshold + stt * k : nullptr);
     }
-    if (!rc && summary && keep) rc = gpirt_sampler_accumulate(s, quadratic);
+    if (!rc && summary && keep)   // samples$theta[-1, , ]: the first kept draw's theta may be left out
+      rc = gpirt_sampler_accumulate(s, (options & GPIRT_SUMMARY_QUADRATIC) |
+                                           ((k == 0 && (options & GPIRT_SUMMARY_DROP_FIRST_THETA)) ? GPIRT_SUMMARY_SKIP_THETA : 0));
     if (keep) ++k;
     if (!rc && cfg->progress && cfg->progress(it + 1, total, cfg->progress_user)) {
       set_error("interrupted by the progress callback at sweep %d", it + 1);

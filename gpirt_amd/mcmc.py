@@ -41,7 +41,7 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, THIN=1, CHAIN=1,
               vote_codes=None, thresholds=None, SEED=1, constant_IRF=0, KERNEL="RBF",
               beta_proposal_sds=None, *, return_f=True, return_fstar=True, theta_mode="ess",
               jitter=1e-6, max_ess_rounds=200, item_range=None, rank=0, world=1, allreduce=None,
-              progress=None, summary=False, summary_quadratic=False, flags=0):
+              progress=None, summary=False, summary_quadratic=False, summary_drop_first_theta=False, flags=0):
     """Run ``CHAIN`` independent chains; returns a list with one dict per chain holding
 
     ``theta [K, n, H]``, ``f [K, n, m, H]``, ``fstar [K, 1001, m, H]``, ``beta [K, 3, m, H]``,
@@ -51,7 +51,9 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, THIN=1, CHAIN=1,
     (gpirt-sythetic.R:153-154).  ``vote_codes`` and ``beta_proposal_sds`` are accepted and
     ignored (legacy arguments, gpirt_CIRI.R:135).  ``summary=True`` adds ``"summary"``: the
     posterior summaries accumulated on the device (``gpirt_amd.post`` turns them into the
-    reference's evaluation metrics), so that ``return_f`` / ``return_fstar`` can be False.
+    reference's evaluation metrics), so that ``return_f`` / ``return_fstar`` can be False;
+    ``summary_drop_first_theta`` leaves the first kept draw out of its theta mean / sd, as the
+    reference's ``samples$theta[-1, i, h]`` does (gpirt-sythetic.R:123).
     ``flags`` is OR-ed into ``gpirt_config.flags`` (e.g. ``_abi.GENERATOR_PRIOR``: the prior
     factor in generator form, see ``include/gpirt.h``).
     """
@@ -116,7 +118,9 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, THIN=1, CHAIN=1,
         if summary:
             from .sampler import fetch_summary
             summ = fetch_summary(cfg, lambda sm: check(lib().gpirt_run_summary(
-                C.byref(cfg), *inp.args(), C.byref(out), C.byref(sm), int(bool(summary_quadratic)))))
+                C.byref(cfg), *inp.args(), C.byref(out), C.byref(sm),
+                (_abi.SUMMARY_QUADRATIC if summary_quadratic else 0) |
+                (_abi.SUMMARY_DROP_FIRST_THETA if summary_drop_first_theta else 0))))
         else:
             check(lib().gpirt_run(C.byref(cfg), *inp.args(), C.byref(out)))
 

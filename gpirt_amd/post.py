@@ -31,12 +31,16 @@ def category_probs(F, thresholds):
     return cdf[..., 1:] - cdf[..., :-1]
 
 
-def summarize_draws(samples, quadratic=False, xs=None):
+def summarize_draws(samples, quadratic=False, xs=None, drop_first_theta=False):
     """The quantities of `gpirt_summary` from kept draws (a chain dict of `gpirtMCMC`):
     ``theta_mean/theta_sd [n,H]`` (:122-123, sd with n-1), ``prob_mean [G,m,H,C]`` and
     ``argmax_mean [G,m,H]`` with F* = fstar + beta_0 + beta_1 xs (:153-154; `quadratic`
-    adds beta_2 xs^2)."""
+    adds beta_2 xs^2).  The reference takes theta's mean and sd over ``samples$theta[-1, i, h]``,
+    i.e. without the first kept draw (:123, :131-132): `drop_first_theta` does the same; the
+    probability sums always run over all draws, as the reference's do (:159-214)."""
     theta = np.asarray(samples["theta"])                  # [K, n, H]
+    if drop_first_theta and theta.shape[0] > 1:
+        theta = theta[1:]
     fstar = np.asarray(samples["fstar"])                  # [K, G, m, H]
     beta = np.asarray(samples["beta"])                    # [K, 3, m, H]
     thr = np.asarray(samples["threshold"])                # [K, m, C+1, H]
@@ -53,7 +57,7 @@ def summarize_draws(samples, quadratic=False, xs=None):
         prob += p
         arg += 1 + np.argmax(p, axis=-1)                  # which.max: first maximum
     return dict(theta_mean=theta.mean(axis=0),
-                theta_sd=theta.std(axis=0, ddof=1) if K > 1 else np.full(theta.shape[1:], np.nan),
+                theta_sd=theta.std(axis=0, ddof=1) if theta.shape[0] > 1 else np.full(theta.shape[1:], np.nan),
                 prob_mean=prob / K, argmax_mean=arg / K, draws=K)
 
 

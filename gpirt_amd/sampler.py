@@ -115,9 +115,11 @@ class Sampler:
         check(lib().gpirt_sampler_diagnostics(self._h, C.byref(o)))
         return int(o.nu_rows_beside_factor)
 
-    def accumulate(self, quadratic=False):
-        """Add the current state to the device-side running sums of the posterior summaries."""
-        check(lib().gpirt_sampler_accumulate(self._h, int(bool(quadratic))))
+    def accumulate(self, quadratic=False, skip_theta=False):
+        """Add the current state to the device-side running sums of the posterior summaries
+        (`skip_theta`: leave theta out of this draw's sums)."""
+        check(lib().gpirt_sampler_accumulate(
+            self._h, (_abi.SUMMARY_QUADRATIC if quadratic else 0) | (_abi.SUMMARY_SKIP_THETA if skip_theta else 0)))
 
     def summary(self):
         """``theta_mean/theta_sd [n,H]``, ``prob_mean [n_grid,m_loc,P,C]``,

@@ -243,7 +243,8 @@ int gpirt_sampler_diagnostics(gpirt_sampler *s, gpirt_outputs *out);
  * (gpirt-sythetic.R:111-133,151-214,231-251; getprob_gpirt.R:1-20), accumulated on the
  * device so that the f / f* draws need not leave it:
  *   theta_mean, theta_sd   pred_theta / pred_theta_sd before centring (:122-123), sd with
- *                          the n-1 divisor of R's sd()
+ *                          the n-1 divisor of R's sd(); over all kept draws, or over all but the
+ *                          first as the reference's `[-1, i, h]` does (GPIRT_SUMMARY_DROP_FIRST_THETA)
  *   prob_mean              mean over draws of P(y = c | x_g) =
  *                          Phi(b_c - F*(x_g)) - Phi(b_{c-1} - F*(x_g)) with
  *                          F* = fstar + beta_0 + beta_1 x_g (:153-154; `quadratic` adds
@@ -260,8 +261,15 @@ typedef struct gpirt_summary {
   double *prob_mean;    /* [n_grid, m_loc, P, C]                                    */
   double *argmax_mean;  /* [n_grid, m_loc, P]   (categories counted from 1)         */
 } gpirt_summary;
+/* Options of the two calls below (OR-ed). */
+enum {
+  GPIRT_SUMMARY_QUADRATIC = 1,        /* F* also gets beta_2 x_g^2                                    */
+  GPIRT_SUMMARY_SKIP_THETA = 2,       /* gpirt_sampler_accumulate: leave theta out of this draw's sums */
+  GPIRT_SUMMARY_DROP_FIRST_THETA = 4  /* gpirt_run_summary: the theta sums leave out the first kept
+                                         draw, as samples$theta[-1, i, h] does (gpirt-sythetic.R:123) */
+};
 /* Add the sampler's current state to the running sums (call after a kept sweep). */
-int gpirt_sampler_accumulate(gpirt_sampler *s, int32_t quadratic);
+int gpirt_sampler_accumulate(gpirt_sampler *s, int32_t options);
 /* Finish the running sums into `out` (they keep accumulating afterwards). */
 int gpirt_sampler_summary(gpirt_sampler *s, gpirt_summary *out);
 /* gpirt_run that also accumulates every kept draw; `summary` may be NULL. */
@@ -269,7 +277,7 @@ int gpirt_run_summary(const gpirt_config *cfg, const int8_t *y, const double *th
                       const double *beta_prior_means, const double *beta_prior_sds,
                       const double *theta_prior_means, const double *theta_prior_sds,
                       const double *thresholds, gpirt_outputs *out, gpirt_summary *summary,
-                      int32_t quadratic);
+                      int32_t options);
 
 /* ---- checkpoint / resume --------------------------------------------------------------
  * Everything a chain needs to continue exactly where it stopped (theta, f, f*, the

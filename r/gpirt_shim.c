@@ -6,8 +6,11 @@
  * Build, on a machine with R:   R CMD SHLIB gpirt_shim.c -I../include -L../gpirt_amd -lgpirt_hip
  * NOT compiled in this repository's build: R is not available in the build image.
  *
- * All work happens on the R main thread; the library calls back into
- * R_CheckUserInterrupt between sweeps through the progress hook.
+ * All work happens on the R main thread.  Between sweeps the library calls the progress hook,
+ * which asks R whether the user has interrupted -- inside R_ToplevelExec, so that R's long jump
+ * stays within the hook -- and returns non-zero if so: gpirt_run then frees the resident sampler
+ * and returns GPIRT_ERR_INTERRUPT, and only after that does this shim raise the R error.  No jump
+ * ever crosses the library's C++ frames and nothing on the device is leaked by Ctrl-C.
  */
 #include <R.h>
 #include <Rinternals.h>
@@ -17,12 +20,12 @@
 
 #include "gpirt.h"
 
+static void check_interrupt(void *unused) { (void)unused; R_CheckUserInterrupt(); }
+
 static int progress_cb(int32_t sweep, int32_t total, void *user) {
   (void)sweep; (void)total; (void)user;
-  R_CheckUserInterrupt();   /* long-jumps out on Ctrl-C; the sampler is freed by the finalizer-free
-                               design below only on normal return, so keep runs short or accept the
-                               leak of one sampler object on interrupt */
-  return 0;
+  /* R_ToplevelExec returns FALSE when the function left through a long jump (an interrupt) */
+  return R_ToplevelExec(check_interrupt, NULL) == FALSE;
 }
 
 static const double *opt_real(SEXP x) { return Rf_isNull(x) ? NULL : REAL(x); }
@@ -69,7 +72,8 @@ SEXP gpirt_run_call(SEXP y_int, SEXP dims, SEXP iters, SEXP hyper, SEXP theta_in
   o.beta = REAL(be); o.threshold = REAL(tr); o.loglik = REAL(ll);
   int rc = gpirt_run(&cfg, y, opt_real(theta_init), opt_real(bpm), opt_real(bps), opt_real(tpm),
                      opt_real(tps), opt_real(thresholds), &o);
-  if (rc != GPIRT_OK) Rf_error("gpirt: %s (status %d)", gpirt_last_error(), rc);
+  if (rc == GPIRT_ERR_INTERRUPT) { UNPROTECT(7); Rf_error("gpirt: interrupted by the user"); }
+  if (rc != GPIRT_OK) { UNPROTECT(7); Rf_error("gpirt: %s (status %d)", gpirt_last_error(), rc); }
   SET_VECTOR_ELT(out, 0, th); SET_VECTOR_ELT(out, 1, f); SET_VECTOR_ELT(out, 2, fs);
   SET_VECTOR_ELT(out, 3, be); SET_VECTOR_ELT(out, 4, tr); SET_VECTOR_ELT(out, 5, ll);
   UNPROTECT(7);

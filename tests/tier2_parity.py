@@ -82,7 +82,7 @@ def oracle_chain(y, C, st, seed):
 
 def metrics(ch, y, train_idx, theta, truth):
     from gpirt_amd import post
-    sm = post.summarize_draws(ch)
+    sm = post.summarize_draws(ch, drop_first_theta=True)       # samples$theta[-1, i, h], :123
     ev = post.evaluate(sm, y, train_idx, theta, truth)
     return {k: float(ev[k]) for k in METRICS}, sm["theta_mean"]
 
