@@ -177,11 +177,20 @@ struct PotrfHook {
   int (*fn)(void *ctx, int o, int oe); void *ctx;
   int (*timer)(void *ctx, int begin, double flop);
 };
-// With defer_super_inverses the off-diagonal blocks of the inverted super-blocks, which only the
-// triangular solves (launch_potrs) read, are left to a later launch_super_inverses call.
+// mode bits:
+//   POTRF_DEFER_INVERSES  the inverted diagonal (super-)blocks, which only callers that multiply by
+//                         them read (launch_potrs, the generator form), are left to a later
+//                         launch_super_inverses call (work may then be null);
+//   POTRF_SUBSTITUTION    the panels below a diagonal block are solved by block substitution from
+//                         the block's inverted 32 x 32 diagonal blocks instead of a product with its
+//                         whole inverse, which the diagonal-block kernel then does not build (a
+//                         quarter of its time, on the factorisation's critical path).
+enum { POTRF_DEFER_INVERSES = 1, POTRF_SUBSTITUTION = 2 };
 int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, int *d_info,
-                 double *work, const PotrfHook *hook = nullptr, bool defer_super_inverses = false);
-int launch_super_inverses(hipStream_t st, const double *L, int n_pad, int batch, double *inv, double *work);
+                 double *work, const PotrfHook *hook = nullptr, int mode = 0);
+// complete_blocks: the factorisation ran with POTRF_SUBSTITUTION (32 x 32 inverses only so far)
+int launch_super_inverses(hipStream_t st, const double *L, int n_pad, int batch, double *inv, double *work,
+                          bool complete_blocks = false);
 // B <- S^-1 B (two blocked triangular solves) for `batch` systems sharing the layout;
 // xtmp holds 4 * SUP * nrhs_pad doubles per system (split-K slabs of the diagonal steps).
 int launch_potrs(hipStream_t st, const double *L, const double *inv, int n_pad, int batch,

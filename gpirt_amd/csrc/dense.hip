@@ -568,7 +568,9 @@ int launch_prefix_blocks(hipStream_t st, double *V, int64_t elems, int nblk) {
 
 // defined in potrf_diag.hip
 int launch_potrf_diag(hipStream_t st, double *S, int n_pad, int kb, int batch, double *inv_diag, int nb,
-                      int *d_info);
+                      int *d_info, bool offdiag);
+int launch_trsm_panel(hipStream_t st, double *S, int n_pad, int kb, int batch, const double *inv_diag);
+int launch_block_inverses(hipStream_t st, const double *S, int n_pad, int batch, double *inv_diag);
 
 // Off-diagonal blocks of the inverted diagonal super-blocks by block substitution: for a
 // lower-triangular [[A,0],[B,C]] the inverse is [[A^-1,0],[-C^-1 B A^-1, C^-1]].
@@ -610,7 +612,11 @@ static int build_super_inverses(hipStream_t st, const double *L, int n_pad, doub
 // next diagonal step beside a trailing update on a second stream was measured and is not
 // faster: the one-workgroup diagonal kernel needs a whole CU's LDS and only starts when the
 // update, which fills every CU, drains.
-int launch_super_inverses(hipStream_t st, const double *L, int n_pad, int batch, double *inv, double *work) {
+int launch_super_inverses(hipStream_t st, const double *L, int n_pad, int batch, double *inv, double *work,
+                          bool complete_blocks) {
+  // after a factorisation with POTRF_SUBSTITUTION the image holds the inverted 32 x 32 diagonal
+  // blocks only: the 128 x 128 inverses come first
+  if (complete_blocks) GP_TRY(launch_block_inverses(st, L, n_pad, batch, inv));
   if (n_pad / TILE > 1)
     for (int z = 0; z < batch; ++z)
       GP_TRY(build_super_inverses(st, L + (int64_t)n_pad * n_pad * z, n_pad, inv + inv_group_elems(n_pad) * z,
@@ -619,10 +625,13 @@ int launch_super_inverses(hipStream_t st, const double *L, int n_pad, int batch,
 }
 
 int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, int *d_info,
-                 double *work, const PotrfHook *hook, bool defer_super_inverses) {
+                 double *work, const PotrfHook *hook, int mode) {
   const int nb = n_pad / TILE;
+  static const bool no_subst = getenv("GPIRT_NO_SUBSTITUTION") != nullptr;
+  const bool subst = (mode & POTRF_SUBSTITUTION) && !no_subst;
   const int64_t sS = (int64_t)n_pad * n_pad, sI = inv_group_elems(n_pad);
   auto panel_solve = [&](int k) -> int {   // L_ik = A_ik * inv(L_kk)^T, i > k
+    if (subst) return launch_trsm_panel(st, S, n_pad, k, batch, inv);
     int rem = nb - 1 - k;
     double *panel = S + (int64_t)(k + 1) * TILE + (int64_t)n_pad * k * TILE;
     GemmArgs p{};
@@ -645,7 +654,7 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
   for (int o = 0; o < nb; o += 4) {
     const int oe = min(o + 4, nb);
     for (int k = o; k < oe; ++k) {
-      GP_TRY(launch_potrf_diag(st, S, n_pad, k, batch, inv, nb, d_info));
+      GP_TRY(launch_potrf_diag(st, S, n_pad, k, batch, inv, nb, d_info, !subst));
       if (k + 1 < nb) GP_TRY(panel_solve(k));
       GP_TRY(update_rect(k, k + 1, oe));
     }
@@ -666,7 +675,7 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
     }
     if (hook && hook->fn) GP_TRY(hook->fn(hook->ctx, o, oe));
   }
-  if (!defer_super_inverses) GP_TRY(launch_super_inverses(st, S, n_pad, batch, inv, work));
+  if (!(mode & POTRF_DEFER_INVERSES)) GP_TRY(launch_super_inverses(st, S, n_pad, batch, inv, work, subst));
   return GPIRT_OK;
 }
 

@@ -118,10 +118,107 @@ __device__ __forceinline__ void store_l_columns(const double *T, double *A, int 
         make_double2(i2 >= c ? T[i2 * XLD + c] : 0.0, i2 + 1 >= c ? T[(i2 + 1) * XLD + c] : 0.0);
 }
 
+// Off-diagonal blocks of X = L^-1 in the LDS image (L in the lower triangle, the inverted
+// 32 x 32 diagonal blocks transposed above it, their diagonals in dinv), for all four waves of the
+// workgroup.  Ends with a barrier.
+__device__ __forceinline__ void inverse_offdiag(double *T, const double *dinv, int wave, int lr, int lk) {
+  // Off-diagonal blocks of X = L^-1 by recursive doubling: for a lower-triangular
+  // [[A,0],[B,C]] the inverse is [[A^-1,0],[-C^-1 B A^-1, C^-1]].  Level 1 fills X_10 and
+  // X_32 (32x32), level 2 the 64x64 block below the first 64 columns.  All products run on
+  // MFMA straight from the image; the inner product M = B A^-1 is parked in the (still
+  // unused) destination region of the result, transposed like the result itself.
+  {
+    // ---- level 1: wave = (pair, column strip of 16) --------------------------------------
+    {
+      const int pair = wave >> 1, cs = wave & 1;
+      const int p0 = 64 * pair, i1 = p0 + SB, c0 = p0 + 16 * cs;
+      v4d m0 = {0.0, 0.0, 0.0, 0.0}, m1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < SB / 4; ++kk) {
+        if (kk < 4 * cs) continue;                       // X_pp is lower-triangular
+        const int k = p0 + 4 * kk + lk;
+        const double bv = x_sel(T, dinv, k, c0 + lr);
+        m0 = mfma4(T[(i1 + lr) * XLD + k], bv, m0);
+        m1 = mfma4(T[(i1 + 16 + lr) * XLD + k], bv, m1);
+      }
+      double *Mt = &T[(c0 + lr) * XLD + i1];             // M[row][col = lr] at Mt[row]
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        Mt[lk + 4 * g] = m0[g];
+        Mt[16 + lk + 4 * g] = m1[g];
+      }
+      double bm[SB / 4];
+#pragma unroll
+      for (int kk = 0; kk < SB / 4; ++kk) bm[kk] = Mt[4 * kk + lk];
+      v4d o0 = {0.0, 0.0, 0.0, 0.0}, o1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < SB / 4; ++kk) {
+        const int k = i1 + 4 * kk + lk;
+        if (kk < 4) o0 = mfma4(x_sel(T, dinv, i1 + lr, k), bm[kk], o0);
+        o1 = mfma4(x_sel(T, dinv, i1 + 16 + lr, k), bm[kk], o1);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        Mt[lk + 4 * g] = -o0[g];
+        Mt[16 + lk + 4 * g] = -o1[g];
+      }
+    }
+    __syncthreads();
+    
+    // ---- level 2, inner product M = L_BA X_AA: wave = 16-row tile of the lower 64 rows -----
+    {
+      const int ti = wave;
+      v4d acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int k = 4 * kk + lk;
+        const double av = T[(64 + 16 * ti + lr) * XLD + k];
+#pragma unroll
+        for (int cs = 0; cs <= kk / 4; ++cs)             // X_AA[k][c] = 0 for k < c
+          acc[cs] = mfma4(av, x_sel(T, dinv, k, 16 * cs + lr), acc[cs]);
+      }
+#pragma unroll
+      for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) T[(16 * cs + lr) * XLD + 64 + 16 * ti + lk + 4 * g] = acc[cs][g];
+    }
+    __syncthreads();
+    
+    // ---- level 2, X_BA = -X_BB M: wave = column strip of 16 (reads and writes only its own
+    // 16 image rows of the parked M) ----------------------------------------------------------
+    {
+      const int cs = wave;
+      double *Mt = &T[(16 * cs + lr) * XLD + 64];
+      double bm[16];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) bm[kk] = Mt[4 * kk + lk];
+      v4d o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int ti = kk / 4; ti < 4; ++ti)              // X_BB is lower-triangular
+          o[ti] = mfma4(x_sel(T, dinv, 64 + 16 * ti + lr, 64 + 4 * kk + lk), bm[kk], o[ti]);
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Mt[16 * ti + lk + 4 * g] = -o[ti][g];
+    }
+    __syncthreads();
+  }
+}
+
 // One workgroup (4 waves) factors a 128x128 block in LDS and inverts the factor, blocked by
 // 32: wave 0 factors and inverts the 32x32 diagonal block in registers, then all four waves
 // apply the panel solve and the trailing update with FP64 MFMA straight from LDS.  The
 // off-diagonal blocks of the inverse follow by block substitution, again on MFMA.
+// OFFDIAG = false leaves the inverse at its 32 x 32 diagonal blocks: enough for the panel solve by
+// substitution (trsm_panel_kernel), a quarter of the kernel's time saved on the critical path;
+// block_inverse_kernel completes the 128 x 128 inverses later for the callers that multiply by them.
+template <bool OFFDIAG>
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S, int n_pad, int kb,
                                                         double *__restrict__ inv_diag, int nb,
                                                         int *__restrict__ info) {
@@ -229,93 +326,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
   __syncthreads();
   STAMP(14);
 
-  // Off-diagonal blocks of X = L^-1 by recursive doubling: for a lower-triangular
-  // [[A,0],[B,C]] the inverse is [[A^-1,0],[-C^-1 B A^-1, C^-1]].  Level 1 fills X_10 and
-  // X_32 (32x32), level 2 the 64x64 block below the first 64 columns.  All products run on
-  // MFMA straight from the image; the inner product M = B A^-1 is parked in the (still
-  // unused) destination region of the result, transposed like the result itself.
-  {
-    // ---- level 1: wave = (pair, column strip of 16) --------------------------------------
-    {
-      const int pair = wave >> 1, cs = wave & 1;
-      const int p0 = 64 * pair, i1 = p0 + SB, c0 = p0 + 16 * cs;
-      v4d m0 = {0.0, 0.0, 0.0, 0.0}, m1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < SB / 4; ++kk) {
-        if (kk < 4 * cs) continue;                       // X_pp is lower-triangular
-        const int k = p0 + 4 * kk + lk;
-        const double bv = x_sel(T, dinv, k, c0 + lr);
-        m0 = mfma4(T[(i1 + lr) * XLD + k], bv, m0);
-        m1 = mfma4(T[(i1 + 16 + lr) * XLD + k], bv, m1);
-      }
-      double *Mt = &T[(c0 + lr) * XLD + i1];             // M[row][col = lr] at Mt[row]
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        Mt[lk + 4 * g] = m0[g];
-        Mt[16 + lk + 4 * g] = m1[g];
-      }
-      double bm[SB / 4];
-#pragma unroll
-      for (int kk = 0; kk < SB / 4; ++kk) bm[kk] = Mt[4 * kk + lk];
-      v4d o0 = {0.0, 0.0, 0.0, 0.0}, o1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < SB / 4; ++kk) {
-        const int k = i1 + 4 * kk + lk;
-        if (kk < 4) o0 = mfma4(x_sel(T, dinv, i1 + lr, k), bm[kk], o0);
-        o1 = mfma4(x_sel(T, dinv, i1 + 16 + lr, k), bm[kk], o1);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        Mt[lk + 4 * g] = -o0[g];
-        Mt[16 + lk + 4 * g] = -o1[g];
-      }
-    }
-    __syncthreads();
-    STAMP(15);
-    // ---- level 2, inner product M = L_BA X_AA: wave = 16-row tile of the lower 64 rows -----
-    {
-      const int ti = wave;
-      v4d acc[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int k = 4 * kk + lk;
-        const double av = T[(64 + 16 * ti + lr) * XLD + k];
-#pragma unroll
-        for (int cs = 0; cs <= kk / 4; ++cs)             // X_AA[k][c] = 0 for k < c
-          acc[cs] = mfma4(av, x_sel(T, dinv, k, 16 * cs + lr), acc[cs]);
-      }
-#pragma unroll
-      for (int cs = 0; cs < 4; ++cs)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) T[(16 * cs + lr) * XLD + 64 + 16 * ti + lk + 4 * g] = acc[cs][g];
-    }
-    __syncthreads();
-    STAMP(16);
-    // ---- level 2, X_BA = -X_BB M: wave = column strip of 16 (reads and writes only its own
-    // 16 image rows of the parked M) ----------------------------------------------------------
-    {
-      const int cs = wave;
-      double *Mt = &T[(16 * cs + lr) * XLD + 64];
-      double bm[16];
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) bm[kk] = Mt[4 * kk + lk];
-      v4d o[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk)
-#pragma unroll
-        for (int ti = kk / 4; ti < 4; ++ti)              // X_BB is lower-triangular
-          o[ti] = mfma4(x_sel(T, dinv, 64 + 16 * ti + lr, 64 + 4 * kk + lk), bm[kk], o[ti]);
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) Mt[16 * ti + lk + 4 * g] = -o[ti][g];
-    }
-    __syncthreads();
-  }
+  if (OFFDIAG) inverse_offdiag(T, dinv, wave, lr, lk);
   STAMP(17);
 
   {
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
     for (int s2 = 0; s2 < 32; ++s2) {
       const int c = cq + 4 * s2;
       // the inverse image's strict upper triangle is zero from its allocation on and stays so
-      if (c <= i2 + 1)
+      if (c <= i2 + 1 && (OFFDIAG || c >= (i2 & ~(SB - 1))))
         *reinterpret_cast<double2 *>(Inv + i2 + SUP * c) =
             make_double2(x_sel(T, dinv, i2, c), x_sel(T, dinv, i2 + 1, c));
     }
@@ -332,10 +343,148 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
   STAMP(18);
 }
 
+// Panel solve by substitution, L_ik = A_ik L_kk^-T for every block row i > k, from the factor's
+// diagonal block and its inverted 32 x 32 diagonal blocks.  One wave owns 16 rows of the panel and
+// keeps their solution transposed in MFMA accumulators, 8 tiles of (16 panel columns x 16 rows):
+// with X^T = L_kk^-1 A^T in 32-column blocks p,
+//   X_p^T = X_pp (A_p^T - sum_{q<p} L_pq X_q^T),
+// every product has its left factor in LDS (read as the MFMA's first operand, 16 consecutive
+// rows of one column per quarter-wave) and its right factor in accumulators -- and a 16x16x4 FP64
+// accumulator register r of a lane is exactly that lane's second operand of k-step r.  The ten
+// 32 x 32 blocks every wave needs (six of L_kk below its diagonal, the four inverted diagonal
+// blocks) are staged once per workgroup with all loads in flight together: 80 KB, so that the
+// workgroup still fits beside a 74 KB workgroup of the GEMM on the same CU.  Element (i, k) of a
+// block sits at k*32 + (i ^ 16 (k & 1)): the two quarter-waves of a fragment read then fall on
+// disjoint halves of the banks.  144 MFMAs per wave, one barrier.
+constexpr int TRSM_BLOCKS = 10;
+__device__ __forceinline__ int trsm_slot(int p, int q) { return p * (p - 1) / 2 + q; }   // L_pq, q < p: 0..5
+__device__ __forceinline__ int trsm_at(int i, int k) { return k * SB + (i ^ ((k & 1) << 4)); }
+
+__global__ __launch_bounds__(256) void trsm_panel_kernel(double *__restrict__ S, int n_pad, int kb,
+                                                         const double *__restrict__ inv_diag) {
+  __shared__ __attribute__((aligned(16))) double blk[TRSM_BLOCKS][SB * SB];
+  const int z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int row0 = (kb + 1) * TILE + 64 * blockIdx.x + 16 * wave;
+  double *Sz = S + (int64_t)n_pad * n_pad * z;
+  const double *Lkk = Sz + (int64_t)kb * TILE * (n_pad + 1);             // diagonal block, ld = n_pad
+  const double *Inv = inv_diag + inv_group_elems(n_pad) * z + inv_block_offset(kb);   // ld = SUP
+  double *P = Sz + row0 + (int64_t)n_pad * kb * TILE;                    // this wave's 16 panel rows
+  // stage the blocks: thread t carries rows (2 (t & 15), +1) of columns (t >> 4) and (t >> 4) + 16
+  double2 st[TRSM_BLOCKS][2];
+  const int si = (tid & 15) << 1, sk = tid >> 4;
+#pragma unroll
+  for (int p = 1; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < p; ++q)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        st[trsm_slot(p, q)][h] = *reinterpret_cast<const double2 *>(Lkk + 32 * p + si + (int64_t)n_pad * (32 * q + sk + 16 * h));
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      st[6 + p][h] = *reinterpret_cast<const double2 *>(Inv + 32 * p + si + (int64_t)SUP * (32 * p + sk + 16 * h));
+  v4d xt[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xt[t][r] = P[lr + (int64_t)n_pad * (16 * t + lk + 4 * r)];
+#pragma unroll
+  for (int b = 0; b < TRSM_BLOCKS; ++b)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)      // rows si, si + 1 stay neighbours under the swizzle (it flips bit 4 only)
+      *reinterpret_cast<double2 *>(&blk[b][trsm_at(si, sk + 16 * h)]) = st[b][h];
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    v4d w[2] = {xt[2 * p], xt[2 * p + 1]};
+#pragma unroll
+    for (int q = 0; q < p; ++q) {
+      const double *Lpq = blk[trsm_slot(p, q)];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const double x = xt[2 * q + (ks >> 2)][ks & 3];
+        const int k = 4 * ks + lk;
+        w[0] = mfma4(-Lpq[trsm_at(lr, k)], x, w[0]);
+        w[1] = mfma4(-Lpq[trsm_at(16 + lr, k)], x, w[1]);
+      }
+    }
+    const double *Xpp = blk[6 + p];
+    v4d o0 = {0.0, 0.0, 0.0, 0.0}, o1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {      // X_pp is lower-triangular: its upper 16 rows stop at column 16
+      const double x = w[ks >> 2][ks & 3];
+      const int k = 4 * ks + lk;
+      if (ks < 4) o0 = mfma4(Xpp[trsm_at(lr, k)], x, o0);
+      o1 = mfma4(Xpp[trsm_at(16 + lr, k)], x, o1);
+    }
+    xt[2 * p] = o0;
+    xt[2 * p + 1] = o1;
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) P[lr + (int64_t)n_pad * (16 * t + lk + 4 * r)] = xt[t][r];
+}
+
+int launch_trsm_panel(hipStream_t st, double *S, int n_pad, int kb, int batch, const double *inv_diag) {
+  const int rows = n_pad - (kb + 1) * TILE;
+  if (rows <= 0) return GPIRT_OK;
+  hipLaunchKernelGGL(trsm_panel_kernel, dim3(rows / 64, batch), dim3(256), 0, st, S, n_pad, kb, inv_diag);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// Completes the inverse of every 128 x 128 diagonal block from its inverted 32 x 32 diagonal
+// blocks (what potrf_diag_kernel<false> leaves): one workgroup per block rebuilds the LDS image
+// (L below, the 32-blocks' inverses transposed above) and runs the same block substitution.
+__global__ __launch_bounds__(256) void block_inverse_kernel(const double *__restrict__ S, int n_pad,
+                                                           double *__restrict__ inv_diag) {
+  __shared__ __attribute__((aligned(16))) double T[TILE * XLD];
+  __shared__ __attribute__((aligned(16))) double dinv[TILE];
+  const int kb = blockIdx.x, z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const double *A = S + (int64_t)n_pad * n_pad * z + (int64_t)kb * TILE * (n_pad + 1);
+  double *Inv = inv_diag + inv_group_elems(n_pad) * z + inv_block_offset(kb);
+  const int i2 = (tid & 63) * 2, cq = tid >> 6;
+  for (int s2 = 0; s2 < 32; ++s2) {
+    const int c = cq + 4 * s2;
+    const double2 l = *reinterpret_cast<const double2 *>(A + i2 + (int64_t)n_pad * c);
+    const double2 x = *reinterpret_cast<const double2 *>(Inv + i2 + (int64_t)SUP * c);
+    const bool same = (c & ~(SB - 1)) == (i2 & ~(SB - 1));       // inside a diagonal 32-block
+    // L strictly below the diagonal stays where it is; the 32-block's inverse goes to the
+    // transposed position above the diagonal, its diagonal to dinv
+    if (i2 >= c) T[i2 * XLD + c] = l.x;
+    if (i2 + 1 >= c) T[(i2 + 1) * XLD + c] = l.y;
+    if (same) {
+      if (i2 > c) T[c * XLD + i2] = x.x; else if (i2 == c) dinv[c] = x.x;
+      if (i2 + 1 > c) T[c * XLD + i2 + 1] = x.y; else if (i2 + 1 == c) dinv[c] = x.y;
+    }
+  }
+  __syncthreads();
+  inverse_offdiag(T, dinv, wave, lr, lk);
+#pragma unroll 8
+  for (int s2 = 0; s2 < 32; ++s2) {
+    const int c = cq + 4 * s2;
+    if (c <= i2 + 1)
+      *reinterpret_cast<double2 *>(Inv + i2 + SUP * c) =
+          make_double2(x_sel(T, dinv, i2, c), x_sel(T, dinv, i2 + 1, c));
+  }
+}
+
+int launch_block_inverses(hipStream_t st, const double *S, int n_pad, int batch, double *inv_diag) {
+  hipLaunchKernelGGL(block_inverse_kernel, dim3(n_pad / TILE, batch), dim3(256), 0, st, S, n_pad, inv_diag);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
 int launch_potrf_diag(hipStream_t st, double *S, int n_pad, int kb, int batch, double *inv_diag, int nb,
-                      int *d_info) {
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, st, S, n_pad, kb, inv_diag, nb,
-                     d_info);
+                      int *d_info, bool offdiag) {
+  if (offdiag)
+    hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(batch), dim3(256), 0, st, S, n_pad, kb, inv_diag, nb, d_info);
+  else
+    hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(batch), dim3(256), 0, st, S, n_pad, kb, inv_diag, nb, d_info);
   GP_HIP(hipGetLastError());
   return GPIRT_OK;
 }

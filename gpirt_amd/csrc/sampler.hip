@@ -931,7 +931,8 @@ static int phase_factor(gpirt_sampler *s) {
                          s->cfg.grid_lo, s->cfg.grid_lo + s->cfg.grid_step * (s->G - 1), s->d_W,
                          (int64_t)s->Np_pad * s->G_pad, s->d_info + 1));
     hook.fn = s->ov_now ? nu_panel_hook : nullptr;
-    GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info, s->d_fwork, &hook, true));
+    GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info, s->d_fwork, &hook,
+                        POTRF_DEFER_INVERSES | POTRF_SUBSTITUTION));
     s->super_inv_ready = 0;
     GP_HIP(hipMemcpyAsync(info3, s->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, s->st));
     GP_HIP(hipStreamSynchronize(s->st));
@@ -1081,7 +1082,7 @@ static int fstar_lowrank_prefactor(gpirt_sampler *s, hipStream_t q) {
 static int ensure_super_inverses(gpirt_sampler *s) {
   if (s->super_inv_ready) return GPIRT_OK;
   s->super_inv_ready = 1;
-  return launch_super_inverses(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_fwork);
+  return launch_super_inverses(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_fwork, true);
 }
 
 static int phase_fstar(gpirt_sampler *s) {
@@ -1713,7 +1714,8 @@ int gpirt_potrf(const double *S, int32_t n, double *L) {
   GP_TRY(dwork.alloc(sizeof(double) * (size_t)potrf_work_elems(np, 1)));
   GP_TRY(dinfo.alloc(sizeof(int)));
   GP_TRY(upload_spd_padded(S, n, np, dS.as<double>()));
-  GP_TRY(launch_potrf(0, dS.as<double>(), np, 1, dI.as<double>(), dinfo.as<int>(), dwork.as<double>()));
+  GP_TRY(launch_potrf(0, dS.as<double>(), np, 1, dI.as<double>(), dinfo.as<int>(), dwork.as<double>(), nullptr,
+                      POTRF_DEFER_INVERSES | POTRF_SUBSTITUTION));    // as the sweep factors
   int info = 0;
   GP_HIP(hipMemcpy(&info, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
   GP_TRY(download_padded(L, n, n, dS.as<double>(), np, 0));
@@ -1942,7 +1944,7 @@ int gpirt_potrf_noalloc(const double *d_S, int64_t lds, int32_t n, double *d_L, 
   GP_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
   hipLaunchKernelGGL(pad_in_kernel, dim3((np + 255) / 256, np), dim3(256), 0, st, d_S, lds, n, S, np);
   GP_HIP(hipGetLastError());
-  GP_TRY(launch_potrf(st, S, np, 1, inv, info, nullptr, nullptr, true));
+  GP_TRY(launch_potrf(st, S, np, 1, inv, info, nullptr, nullptr, POTRF_DEFER_INVERSES | POTRF_SUBSTITUTION));
   hipLaunchKernelGGL(tril_out_kernel, dim3((n + 255) / 256, n), dim3(256), 0, st, S, np, n, d_L, ldl);
   GP_HIP(hipGetLastError());
   int h_info = 0;
