@@ -161,8 +161,8 @@ def cpu_baseline(args, n, m, G):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", "--respondents", dest="n", type=int, default=10000)
     ap.add_argument("--m", "--items", dest="m", type=int, default=4096)
     ap.add_argument("--C", type=int, default=5)

@@ -22,6 +22,7 @@ THETA_TABLE = 16
 THETA_DIRECT = 32
 FSTAR_SOLVE = 64
 GENERATOR_PRIOR = 128
+INDEX_TRUNCATE = 512
 NO_NU_OVERLAP = 256
 
 SUMMARY_QUADRATIC, SUMMARY_SKIP_THETA, SUMMARY_DROP_FIRST_THETA = 1, 2, 4

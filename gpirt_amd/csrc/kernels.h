@@ -76,6 +76,7 @@ struct ThetaArgs {
   int from_parts;           // the decision kernel sums `part` itself instead of reading `buf`
   int n, H, C, mloc, ML, U_pad, G, constant_irf, R;
   double grid_lo, grid_step;
+  int index_truncate;       // grid index = floor instead of nearest
   double os2;               // prior variance of the static step (theta_os^2, 1 when theta_os = 0)
   uint64_t seed; uint32_t sweep;
   int32_t *remaining;       // [R+4] respondents still active after the decision of round r; the last
@@ -115,8 +116,8 @@ int launch_summary_theta(hipStream_t st, const double *theta, int64_t count, dou
 int launch_summary_prob(hipStream_t st, const ThetaArgs &a, int quadratic, double *psum, double *asum);
 // f[r + ld*u] = Gt[u + U_pad * idx(x_p[r])]   (main.m:69-73)
 int launch_snap(hipStream_t st, const double *Gt, int U_pad, const double *x, int64_t x_stride,
-                int Np, int P, int mloc, int ML, int G, double lo, double step, double *f,
-                int64_t ld);
+                int Np, int P, int mloc, int ML, int G, double lo, double step, int truncate,
+                double *f, int64_t ld);
 // out[g + G*(jl + mloc*p)] = Gt[(jl + ML*p) + U_pad*g]
 int launch_export_fstar(hipStream_t st, const double *Gt, int U_pad, int G, int P, int mloc, int ML,
                         double *out);

@@ -157,7 +157,8 @@ struct gpirt_sampler {
   int h_info2;               // host copy of the status of this sweep's low-rank f* factorisation
   int fs_nodes, fs_rank;     // nodes in use and their padded count (0: exact cross-covariance)
   int summary_draws, summary_theta_draws;
-  int32_t *d_done, *d_info, *d_remaining;
+  int32_t *d_done, *d_info, *d_remaining;   // d_remaining = d_info + 4: one block, one copy per look
+  int32_t *h_look;                           // pinned host mirror of that block
   unsigned long long *d_counters;  // [3][2]: f, param, theta x (evaluations, capped)
   int64_t theta_rounds;
   int jitter_retries;
@@ -197,12 +198,13 @@ static void sampler_free(gpirt_sampler *s) {
                   s->d_Gt, s->d_ebeta, s->d_delta, s->d_beta, s->d_bthr, s->d_betaS, s->d_bthrS,
                   s->d_bpm, s->d_bps, s->d_xc, s->d_tnu, s->d_prop, s->d_hh, s->d_phi, s->d_pmin,
                   s->d_pmax, s->d_buf, s->d_Lt, s->d_tpm, s->d_tps, s->d_llu, s->d_done, s->d_info,
-                  s->d_remaining, s->d_counters, s->d_onehot, s->d_T, s->d_lp,
+                  s->d_counters, s->d_onehot, s->d_T, s->d_lp,
                   s->d_sum_th, s->d_sum_th2, s->d_sum_p, s->d_sum_arg, s->d_nodes, s->d_lag, s->d_tab,
                   s->d_part, s->d_gidx, s->d_order, s->d_bstart, s->d_ghist, s->d_nuparts,
                   s->d_bw, s->d_B, s->d_BL, s->d_feat, s->d_Mm, s->d_minv, s->d_X, s->d_gparts,
                   s->d_Jb, s->d_jinv, s->d_Tb, s->d_Sbb, s->d_linv, s->d_Et, s->d_Wt, s->d_V};
   for (void *p : ptrs) if (p) (void)hipFree(p);
+  if (s->h_look) (void)hipHostFree(s->h_look);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->upd_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_panel) (void)hipEventDestroy(e);
@@ -561,7 +563,13 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   A_(s->d_Lt, (size_t)H * H);
   A_(s->d_tpm, 2 * (size_t)n); A_(s->d_tps, 2 * (size_t)n);
   A_(s->d_llu, U_pad);
-  A_(s->d_done, n); A_(s->d_info, 3); A_(s->d_remaining, (size_t)(s->cfg.max_ess_rounds + 4));
+  A_(s->d_done, n); A_(s->d_info, (size_t)(4 + s->cfg.max_ess_rounds + 4));
+  s->d_remaining = s->d_info + 4;
+  if (hipHostMalloc((void **)&s->h_look, sizeof(int32_t) * (size_t)(4 + s->cfg.max_ess_rounds + 4)) != hipSuccess) {
+    set_error("pinned host buffer: allocation failed");
+    return fail(GPIRT_ERR_HIP);
+  }
+  memset(s->h_look, 0, sizeof(int32_t) * (size_t)(4 + s->cfg.max_ess_rounds + 4));
   A_(s->d_counters, 6);
   // nu = L Z with few column tiles (a rank's share of the items, or a handful of items): the
   // longest row panel alone would set the time and most CUs would hold one workgroup or none,
@@ -763,19 +771,13 @@ static int update_timer(void *ctx, int begin, double flop) {
 static int phase_factor_generator(gpirt_sampler *s, int *done) {
   *done = 0;
   GP_TRY(mark(s, PH_KBUILD));
-  int info3[3] = {0, 0, 0};
-  GP_HIP(hipMemcpyAsync(info3 + 2, s->d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s->st));
   GP_HIP(hipMemsetAsync(s->d_info, 0, 3 * sizeof(int), s->st));
   GP_TRY(launch_bary(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->d_nodes, s->d_bw, s->fs_nodes,
                      s->cfg.grid_lo, s->cfg.grid_lo + s->cfg.grid_step * (s->G - 1), s->d_W,
                      (int64_t)s->Np_pad * s->G_pad, s->d_info + 1));
-  GP_HIP(hipMemcpyAsync(info3 + 1, s->d_info + 1, sizeof(int), hipMemcpyDeviceToHost, s->st));
+  GP_HIP(hipMemcpyAsync(s->h_look, s->d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, s->st));
   GP_HIP(hipStreamSynchronize(s->st));
-  if (info3[2]) {
-    set_error("low-rank f* step: s2 I + Phi^T Phi is not positive definite (pivot %d)", info3[2]);
-    return GPIRT_ERR_NOT_PD;
-  }
-  if (info3[1]) return GPIRT_OK;
+  if (s->h_look[1]) return GPIRT_OK;
   s->theta_inside = 1;
   GP_TRY(mark(s, PH_POTRF));
   const int nblk = s->Np_pad / TILE;
@@ -816,9 +818,9 @@ static int phase_factor_generator(gpirt_sampler *s, int *done) {
   w.C = s->d_Wt; w.ldc = TILE; w.strideC = blk;
   w.M = TILE; w.N = TILE; w.K = TILE; w.batch = nblk; w.alpha = sd; w.beta = 0.0;
   GP_TRY(launch_gemm(s->st, false, false, w));
-  int info = 0;
-  GP_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, s->st));
+  GP_HIP(hipMemcpyAsync(s->h_look, s->d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, s->st));
   GP_HIP(hipStreamSynchronize(s->st));
+  const int info = s->h_look[0];
   // a block that is not positive definite: this sweep takes the dense route, which escalates
   // the jitter and counts the retries
   if (info) return GPIRT_OK;
@@ -921,10 +923,8 @@ static int phase_factor(gpirt_sampler *s) {
       s->z_filled = 1;
     }
     GP_TRY(mark(s, PH_POTRF));
-    // info[0]: pivot of a failed factorisation; [1]: an input outside the range of the f*
-    // nodes; [2]: the 128 x 128 factorisation of the previous sweep's low-rank f* step
-    int info3[3] = {0, 0, 0};
-    GP_HIP(hipMemcpyAsync(info3 + 2, s->d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    // info[0]: pivot of a failed factorisation; [1]: an input outside the range of the f* nodes
+    // ([2], the status of the low-rank f* step's factorisation, is read behind that step)
     GP_HIP(hipMemsetAsync(s->d_info, 0, 3 * sizeof(int), s->st));
     if (s->fs_lowrank)   // the Lagrange basis at the inputs; it waits in W, which is free until the f* step
       GP_TRY(launch_bary(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->d_nodes, s->d_bw, s->fs_nodes,
@@ -934,14 +934,10 @@ static int phase_factor(gpirt_sampler *s) {
     GP_TRY(launch_potrf(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_info, s->d_fwork, &hook,
                         POTRF_DEFER_INVERSES | POTRF_SUBSTITUTION));
     s->super_inv_ready = 0;
-    GP_HIP(hipMemcpyAsync(info3, s->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, s->st));
+    GP_HIP(hipMemcpyAsync(s->h_look, s->d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, s->st));
     GP_HIP(hipStreamSynchronize(s->st));
-    if (info3[2]) {
-      set_error("low-rank f* step: s2 I + Phi^T Phi is not positive definite (pivot %d)", info3[2]);
-      return GPIRT_ERR_NOT_PD;
-    }
-    s->theta_inside = !info3[1];
-    const int info = info3[0];
+    s->theta_inside = !s->h_look[1];
+    const int info = s->h_look[0];
     if (!info) {
       GP_TRY(overlap_tune(s));
       s->dense_sweeps++;
@@ -1206,6 +1202,7 @@ static ThetaArgs theta_args(gpirt_sampler *s) {
   a.bthrS = s->d_bthrS; a.yT = s->d_yT; a.n = s->n; a.H = s->H; a.C = s->C; a.mloc = s->mloc;
   a.ML = s->ML; a.U_pad = s->U_pad; a.G = s->G; a.constant_irf = s->cfg.constant_irf;
   a.R = s->cfg.max_ess_rounds; a.grid_lo = s->cfg.grid_lo; a.grid_step = s->cfg.grid_step;
+  a.index_truncate = (s->cfg.flags & GPIRT_INDEX_TRUNCATE) ? 1 : 0;
   a.seed = s->seed; a.sweep = s->sweep; a.remaining = s->d_remaining;
   a.counters = s->d_counters + 4;
   a.tab = s->d_tab;
@@ -1230,7 +1227,7 @@ static int exchange(gpirt_sampler *s, double *buf = nullptr, int64_t count = 0) 
 
 // Lock-step rounds of THETA_SPEC proposals each.  The decision kernel of a round leaves the
 // number of respondents still active in remaining[round]; the host looks at that history only
-// after the second round and then after every round (a look is a stream drain plus a launch
+// after every second round (a look is a stream drain, one copy into pinned memory and a launch
 // gap), except with sharded items and a blocking hook, where every round passes through the
 // host for the exchange anyway.
 static int phase_theta(gpirt_sampler *s) {
@@ -1264,19 +1261,20 @@ static int phase_theta(gpirt_sampler *s) {
   int r = 1;
   bool finished = false;
   while (r <= max_rounds && !finished) {
-    const int last = sharded ? r : min(max_rounds, r < 2 ? 2 : r);
+    // a round nobody needs any more costs three kernels that return at once, less than a look
+    const int last = sharded ? r : min(max_rounds, r < 2 ? 2 : r + 1);
     const bool wide = many_items || active * 4 <= s->n;
     for (int q = r; q <= last; ++q) {
       GP_TRY(eval(0, wide));
       GP_TRY(exchange(s, s->d_buf, (int64_t)THETA_SPEC * s->n));
       GP_TRY(launch_theta_decide(s->st, a, 1 + (q - 1) * THETA_SPEC, q));
     }
-    GP_HIP(hipMemcpyAsync(hist.data() + r, s->d_remaining + r, sizeof(int) * (size_t)(last - r + 1),
-                          hipMemcpyDeviceToHost, s->st));
-    GP_HIP(hipMemcpyAsync(hist.data() + R + 3, s->d_remaining + R + 3, sizeof(int), hipMemcpyDeviceToHost,
-                          s->st));
-    if (s->fs_lowrank) GP_HIP(hipMemcpyAsync(&s->h_info2, s->d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    // one copy into pinned memory brings the status words and the whole history of active counts
+    GP_HIP(hipMemcpyAsync(s->h_look, s->d_info, sizeof(int) * (size_t)(4 + R + 4), hipMemcpyDeviceToHost, s->st));
     GP_HIP(hipStreamSynchronize(s->st));
+    for (int q = r; q <= last; ++q) hist[q] = s->h_look[4 + q];
+    hist[(size_t)R + 3] = s->h_look[4 + R + 3];
+    if (s->fs_lowrank) s->h_info2 = s->h_look[2];
     GP_TRY(fstar_status(s));
     for (int q = r; q <= last; ++q) {
       active = hist[q];
@@ -1312,7 +1310,8 @@ static int phase_snap(gpirt_sampler *s) {
   Range range("gpirt:snap");
   GP_TRY(mark(s, PH_SNAP));
   GP_TRY(launch_snap(s->st, s->d_Gt, s->U_pad, s->d_theta, s->Np, s->Np, s->P, s->mloc, s->ML, s->G,
-                     s->cfg.grid_lo, s->cfg.grid_step, s->d_f, s->Np_pad));
+                     s->cfg.grid_lo, s->cfg.grid_step, (s->cfg.flags & GPIRT_INDEX_TRUNCATE) ? 1 : 0, s->d_f,
+                     s->Np_pad));
   return GPIRT_OK;
 }
 
@@ -1339,9 +1338,10 @@ int gpirt_sampler_sweep(gpirt_sampler *s, int32_t sweeps) {
   // the last sweep's f* status would otherwise be seen by the next call only (grid-mode
   // respondent steps never look at it inside the sweep)
   if (s->fs_lowrank && sweeps > 0)
-    GP_HIP(hipMemcpyAsync(&s->h_info2, s->d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    GP_HIP(hipMemcpyAsync(s->h_look, s->d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, s->st));
   GP_HIP(hipStreamSynchronize(s->st));
   GP_TRY(collect_times(s));
+  if (s->fs_lowrank && sweeps > 0) s->h_info2 = s->h_look[2];
   GP_TRY(fstar_status(s));
   return GPIRT_OK;
 }

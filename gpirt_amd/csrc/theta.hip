@@ -2,7 +2,8 @@
 //
 // Each respondent's trajectory theta_i[1..H] gets one elliptical-slice update
 // (utils/elliptical_slice.m:47-102) under the temporal GP prior, with the likelihood read
-// off the grid: f* is looked up at the nearest grid point (the index rule of main.m:69) and
+// off the grid: f* is looked up at the nearest grid point (the index rule of main.m:69; on request
+// at the grid point below, the rule of gpirt-sythetic.R:190) and
 // the ordinal-probit cell of log_like_fn.m:3-4 / gpirt-sythetic.R:159-167 is summed over
 // this rank's items.  All respondents advance in lock-step rounds so that, when items are
 // sharded over GPUs, one n-vector sum-all-reduce per round is the only exchange.
@@ -11,8 +12,10 @@
 
 namespace gpirt {
 
-__device__ inline int grid_index(double x, double lo, double step, int G) {
-  double r = rint((x - lo) / step);
+// nearest grid point (main.m:69), or the grid point at or below x (gpirt-sythetic.R:190)
+__device__ inline int grid_index(double x, double lo, double step, int G, int truncate) {
+  const double t = (x - lo) / step;
+  double r = truncate ? floor(t) : rint(t);
   if (!(r > 0.0)) return 0;
   if (r > (double)(G - 1)) return G - 1;
   return (int)r;
@@ -25,7 +28,7 @@ __device__ inline double prior_mean(const double *tpm, int i, int h) {
 // bucketed evaluation (H = 1): the kernel that fixes the theta to be evaluated next also
 // files the respondent under that theta's grid index
 __device__ inline void bucket_note(const ThetaArgs &a, int v, double th) {
-  const int g = grid_index(th, a.grid_lo, a.grid_step, a.G);
+  const int g = grid_index(th, a.grid_lo, a.grid_step, a.G, a.index_truncate);
   a.gidx[v] = g;
   atomicAdd(&a.ghist[g], 1);
 }
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initia
   prod.reset();
   for (int h = 0; h < H; ++h) {
     double th = initial ? a.theta[i + (int64_t)n * h] : a.prop[v + V * h] + prior_mean(a.tpm, i, h);
-    const int g = grid_index(th, a.grid_lo, a.grid_step, a.G);
+    const int g = grid_index(th, a.grid_lo, a.grid_step, a.G, a.index_truncate);
     const double xg = a.grid_lo + a.grid_step * g;
     const int p = a.constant_irf ? 0 : h;
     const double *Gr = a.Gt + (int64_t)U_pad * g + (int64_t)ML * p;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void theta_eval_table_kernel(ThetaArgs a, int 
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   for (int h = 0; h < H; ++h) {
     double th = initial ? a.theta[i + (int64_t)n * h] : a.prop[v + V * h] + prior_mean(a.tpm, i, h);
-    const int g = grid_index(th, a.grid_lo, a.grid_step, a.G);
+    const int g = grid_index(th, a.grid_lo, a.grid_step, a.G, a.index_truncate);
     const int p = a.constant_irf ? 0 : h;
     const double *row = a.tab + U_pad * a.C * g + (int64_t)ML * p;
     const int8_t *yr = a.yT + (int64_t)ML * H * i + (int64_t)ML * h;
@@ -589,7 +592,8 @@ int launch_summary_prob(hipStream_t st, const ThetaArgs &a, int quadratic, doubl
 __global__ __launch_bounds__(256) void snap_kernel(const double *__restrict__ Gt, int U_pad,
                                                    const double *__restrict__ x, int64_t x_stride,
                                                    int Np, int mloc, int ML, int G, double lo,
-                                                   double step, double *__restrict__ f, int64_t ld) {
+                                                   double step, int truncate, double *__restrict__ f,
+                                                   int64_t ld) {
   __shared__ double tile[64][65];
   __shared__ int gidx[64];
   const int p = blockIdx.z;
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(256) void snap_kernel(const double *__restrict__ Gt
   const int tid = threadIdx.x;
   if (tid < 64) {
     int r = r0 + tid;
-    gidx[tid] = r < Np ? grid_index(x[x_stride * p + r], lo, step, G) : 0;
+    gidx[tid] = r < Np ? grid_index(x[x_stride * p + r], lo, step, G, truncate) : 0;
   }
   __syncthreads();
   const int ul = tid & 63;
@@ -614,11 +618,11 @@ __global__ __launch_bounds__(256) void snap_kernel(const double *__restrict__ Gt
 }
 
 int launch_snap(hipStream_t st, const double *Gt, int U_pad, const double *x, int64_t x_stride,
-                int Np, int P, int mloc, int ML, int G, double lo, double step, double *f,
-                int64_t ld) {
+                int Np, int P, int mloc, int ML, int G, double lo, double step, int truncate,
+                double *f, int64_t ld) {
   dim3 grid((Np + 63) / 64, (mloc + 63) / 64, P);
   hipLaunchKernelGGL(snap_kernel, grid, dim3(256), 0, st, Gt, U_pad, x, x_stride, Np, mloc, ML, G, lo,
-                     step, f, ld);
+                     step, truncate, f, ld);
   GP_HIP(hipGetLastError());
   return GPIRT_OK;
 }

@@ -79,9 +79,12 @@ enum {
                               from 4096 inputs on, the first rows of it are computed beside the
                               factorisation on a second stream (same result bit for bit) when the
                               sampler's own timing of its first sweeps finds that faster         */
-  GPIRT_GENERATOR_PRIOR = 128 /* keep the Cholesky factor of K(theta,theta) + s2 I in generator
+  GPIRT_GENERATOR_PRIOR = 128, /* keep the Cholesky factor of K(theta,theta) + s2 I in generator
                               (block semiseparable) form instead of as an n x n matrix (see
                               gpirt_sampler_sweep); one IRF group only, ignored otherwise      */
+  GPIRT_INDEX_TRUNCATE = 512  /* look f* up at the grid point at or below theta, the rule of the
+                              R post-processing (gpirt-sythetic.R:190), instead of at the
+                              nearest one (main.m:69, the default)                             */
 };
 
 /* Sum-all-reduce hook used by the respondent step when items are sharded over

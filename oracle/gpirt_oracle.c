@@ -361,7 +361,7 @@ static void params_from_white(const orc_sampler *s, int u, const double *e, cons
 
 static inline int grid_index(const orc_sampler *s, double x) {
   double t = (x - s->cfg.grid_lo) / s->cfg.grid_step;
-  double r = rint(t);
+  double r = (s->cfg.flags & GPIRT_INDEX_TRUNCATE) ? floor(t) : rint(t);   /* gpirt-sythetic.R:190 : main.m:69 */
   if (!(r > 0.0)) return 0;
   if (r > (double)(s->G - 1)) return s->G - 1;
   return (int)r;

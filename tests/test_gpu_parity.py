@@ -184,7 +184,9 @@ def assert_states_agree(sg, sc, tag=None):
                                                  ("2PL_C_5", 5, 1, _abi.GENERATOR_PRIOR),
                                                  ("2PL_C_2", 2, 0, _abi.THETA_TABLE),
                                                  ("Wiener_C_5", 5, 0, _abi.THETA_TABLE),
-                                                 ("2PL_C_5", 5, 1, _abi.THETA_TABLE)])
+                                                 ("2PL_C_5", 5, 1, _abi.THETA_TABLE),
+                                                 ("Wiener_C_5", 5, 0, _abi.INDEX_TRUNCATE),
+                                                 ("2PL_C_5", 5, 1, _abi.INDEX_TRUNCATE | _abi.THETA_TABLE)])
 def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const, flags):
     """Three whole sweeps from the same state with the shared generator: every accept /
     shrink decision must coincide, so the states agree to rounding (theta, beta, thresholds:
@@ -210,6 +212,7 @@ def test_sweep_matches_oracle_on_reference_fixtures(stem, C, const, flags):
                                               (2100, 5, 1, _abi.GENERATOR_PRIOR),
                                               (1300, 9, 2, _abi.GENERATOR_PRIOR),
                                               (1300, 9, 2, _abi.THETA_DIRECT),
+                                              (1300, 9, 2, _abi.INDEX_TRUNCATE),    # bucketed table rows
                                               (1100, 2100, 1, 0)])   # two item chunks per table row
 def test_sweep_matches_oracle_wide_units(n, m, sweeps, flags):
     """n >= 1024 rows per unit switches the item kernels to one workgroup per unit and the
