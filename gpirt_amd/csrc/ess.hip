@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64 * WPB) void loglik_unit_kernel(
     const double *__restrict__ g, int64_t ldg, const int8_t *__restrict__ y, int64_t ldy,
     const double *__restrict__ bthr, int n, int U, int C, double *__restrict__ ll_unit) {
   __shared__ double sb[WPB][MAXC + 2];
-  __shared__ double sphi[PHI_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
   phi_table_to_lds(sphi);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -48,7 +48,7 @@ __global__ void loglik_row_kernel(const double *__restrict__ g, int64_t ldg,
                                   const int8_t *__restrict__ y, int64_t ldy,
                                   const double *__restrict__ bthr, int n, int U, int C,
                                   double *__restrict__ ll_row) {
-  __shared__ double sphi[PHI_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
   phi_table_to_lds(sphi);
   __syncthreads();
   int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -175,36 +175,54 @@ __device__ inline bool surely_rejected(int e, double hh, int *redi, int w) {
 // ---------------------------------------------------------------------------------------
 // slice update of f (a4 + a5)
 // ---------------------------------------------------------------------------------------
+// Element r of a column whose base address is uniform over the wave, through a 32-bit byte
+// offset: the load then takes the base from scalar registers and one vector register of offset
+// (a 64-bit index costs four extra vector instructions per load).
+__device__ inline double col_at(const double *base, uint32_t r) {
+  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (r << 3));
+}
+__device__ inline int col_at(const int8_t *base, uint32_t r) {
+  return *reinterpret_cast<const int8_t *>(reinterpret_cast<const char *>(base) + r);
+}
+
+// Software-pipelined and branch-free: the loads of the next row are in flight while the
+// current cell is evaluated (a wave that waits for y before it asks for f pays two memory
+// round trips per row, and four waves per SIMD do not hide that).  Two rows per trip, each with
+// its own set of registers, so that nothing is copied from "next" to "current".  Indices past
+// the end are clamped to the last row and their cells masked out.
+// `xm` holds the mean itself (b0 = 0, b1 = 1, b2 = 0) or the inputs of the quadratic mean.
 template <int WPU>
 __device__ inline double ll_f_pass(const double *__restrict__ f, const double *__restrict__ nu,
-                                   const double *__restrict__ mu, const double *__restrict__ x,
-                                   double b0, double b1, double b2, const int8_t *__restrict__ y,
-                                   const double *sb, const double *sphi, int n, int row0, double c,
-                                   double s, double *red, int w, double hh, int (*redi)[WPB], int &cp) {
-  // Software-pipelined and branch-free: the loads of the next row are in flight while the
-  // current cell is evaluated (a wave that waits for y before it asks for f pays two memory
-  // round trips per row, and four waves per SIMD do not hide that).  Indices past the end
-  // are clamped to the last row and their cells masked out.
+                                   const double *__restrict__ xm, double b0, double b1, double b2,
+                                   const int8_t *__restrict__ y, const double *sb, const double *sphi,
+                                   int n, int row0, double c, double s, double *red, int w, double hh,
+                                   int (*redi)[WPB], int &cp) {
   LogProduct prod;
   prod.reset();
-  const int stride = 64 * WPU, iters = (n + stride - 1) / stride;   // uniform over the unit
-  const int rc = min(row0, n - 1);
-  int yy = y[rc];
-  double fr = f[rc], nr = nu[rc], xr = mu ? mu[rc] : x[rc];
-  int r = row0;
-  for (int it = 0; it < iters; ++it, r += stride) {
-    const int rn = min(r + stride, n - 1);
-    const int yn = y[rn];
-    const double fn = f[rn], nn = nu[rn], xn = mu ? mu[rn] : x[rn];
-    const double m_r = mu ? xr : b0 + b1 * xr + b2 * xr * xr;
-    const double gg = m_r + (fr * c + nr * s);
+  const uint32_t stride = 64 * WPU, last = (uint32_t)(n - 1);
+  const int iters = (n + (int)stride - 1) / (int)stride;   // uniform over the unit
+  auto cell = [&](int yy, double fr, double nr, double xr, uint32_t r) {
+    const double gg = (b0 + b1 * xr + b2 * xr * xr) + (fr * c + nr * s);
     const int yc = max(yy, 1);
     const double p = ordinal_cell_prob(sb[yc - 1] - gg, sb[yc] - gg, sphi);
-    prod.mul(yy > 0 && r < n ? p : 1.0);
-    if ((it & (SLICE_CHECK - 1)) == SLICE_CHECK - 1 && it + 1 < iters && hh > -INFINITY &&
+    prod.mul(yy > 0 && r <= last ? p : 1.0);
+  };
+  uint32_t r = (uint32_t)row0;
+  const uint32_t r0 = min(r, last);
+  int ya = col_at(y, r0);
+  double fa = col_at(f, r0), na = col_at(nu, r0), xa = col_at(xm, r0);
+  for (int it = 0; it < iters; it += 2, r += 2 * stride) {
+    const uint32_t r1 = min(r + stride, last);
+    const int yb = col_at(y, r1);
+    const double fb = col_at(f, r1), nb = col_at(nu, r1), xb = col_at(xm, r1);
+    cell(ya, fa, na, xa, r);
+    const uint32_t r2 = min(r + 2 * stride, last);
+    ya = col_at(y, r2);
+    fa = col_at(f, r2); na = col_at(nu, r2); xa = col_at(xm, r2);
+    cell(yb, fb, nb, xb, r + stride);
+    if ((it & (SLICE_CHECK - 1)) == SLICE_CHECK - 2 && it + 2 < iters && hh > -INFINITY &&
         surely_rejected<WPU>(prod.e, hh, redi[cp++ & 1], w))
       return -INFINITY;
-    yy = yn; fr = fn; nr = nn; xr = xn;
   }
   return unit_sum<WPU>(prod.log_value(), red, w);
 }
@@ -212,14 +230,15 @@ __device__ inline double ll_f_pass(const double *__restrict__ f, const double *_
 template <int WPU>
 __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
   __shared__ double sbb[WPB][MAXC + 2];
-  __shared__ double sphi[PHI_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
   __shared__ double red[WPB];
   __shared__ int redi[2][WPB];
   phi_table_to_lds(sphi);
   __syncthreads();
   int cp = 0;   // checks so far: consecutive checks alternate between the two exchange slots
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int u = WPU == 1 ? blockIdx.x * WPB + w : blockIdx.x;
+  // the unit is the same for every lane of a wave: say so, and its columns' addresses stay scalar
+  const int u = WPU == 1 ? __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + w) : blockIdx.x;
   if (u >= a.U_pad || u % a.ML >= a.mloc) return;    // uniform over the workgroup when WPU = 4
   double *sb = sbb[WPU == 1 ? w : 0];
   const int C = a.C, n = a.Np;
@@ -234,13 +253,16 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
   const double *x = a.x ? a.x + a.x_stride * (u / a.ML) : nullptr;
   double b0 = 0, b1 = 0, b2 = 0;
   if (a.beta) { b0 = a.beta[3 * u]; b1 = a.beta[3 * u + 1]; b2 = a.beta[3 * u + 2]; }
+  // a mean given row by row goes through the same expression: 0 + 1 * mu + 0 * mu^2 = mu exactly
+  const double *xm = mu ? mu : x;
+  if (mu) { b0 = 0.0; b1 = 1.0; b2 = 0.0; }
   const uint32_t ug = (uint32_t)((a.j0 + u % a.ML) + a.m * (u / a.ML));
   const double *un = a.unif ? a.unif + (int64_t)(a.R + 2) * u : nullptr;
   auto draw = [&](int d) -> double {
     return un ? un[d] : rng_uniform_at(a.seed, TAG_F_U, a.sweep, ug, (uint32_t)d);
   };
 
-  const double cur = ll_f_pass<WPU>(f, nu, mu, x, b0, b1, b2, y, sb, sphi, n, row0, 1.0, 0.0, red, w,
+  const double cur = ll_f_pass<WPU>(f, nu, xm, b0, b1, b2, y, sb, sphi, n, row0, 1.0, 0.0, red, w,
                                     -INFINITY, redi, cp);
   const double hh = log(draw(0)) + cur;              // elliptical_slice.m:66
   double phi = draw(1) * kTwoPi;                     // :72
@@ -250,7 +272,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
   double l = cur, c = 1.0, s = 0.0;
   while (r < a.R) {
     sincos(phi, &s, &c);
-    l = ll_f_pass<WPU>(f, nu, mu, x, b0, b1, b2, y, sb, sphi, n, row0, c, s, red, w, hh, redi, cp);  // :85-86
+    l = ll_f_pass<WPU>(f, nu, xm, b0, b1, b2, y, sb, sphi, n, row0, c, s, red, w, hh, redi, cp);  // :85-86
     ++r;
     if (l > hh) { ok = true; break; }                // :87
     if (phi > 0.0) pmax = phi;                       // :92-96
@@ -288,20 +310,25 @@ int launch_ess_f(hipStream_t st, const EssFArgs &a) {
 // b_c = b_{c-1} + exp(delta_c)), prior N(0,I); a switched-off coefficient and fixed
 // thresholds do not move.
 // ---------------------------------------------------------------------------------------
-constexpr int MAXD = MAXC + 2;
+// The vector lives one element per lane (lane k < C + 2 owns element k): nothing of it occupies
+// registers during the row loop, and the exponentials of a proposal are one call, not C - 2.
+__device__ inline double lane_value(double v, int k) { return __shfl(v, k, 64); }
 
-__device__ inline void params_from_white(const double *v, const double *pm, const double *ps, int C,
+// (beta, thresholds) of the vector `pv`; lanes 0..2 hold the coefficients' prior mean and sd in
+// pm_k, ps_k.  The thresholds accumulate left to right, every lane doing the same additions.
+__device__ inline void params_from_white(double pv, double pm_k, double ps_k, int C, int lane,
                                          double &b0, double &b1, double &b2, double *sb) {
-  b0 = pm[0] + ps[0] * v[0];
-  b1 = pm[1] + ps[1] * v[1];
-  b2 = pm[2] + ps[2] * v[2];
-  double acc = v[3];
-  sb[0] = -INFINITY;
-  sb[1] = acc;
-#pragma unroll
-  for (int c = 2; c < MAXC; ++c)
-    if (c < C) { acc += exp(v[c + 2]); sb[c] = acc; }
-  sb[C] = INFINITY;
+  const double bk = pm_k + ps_k * pv;
+  b0 = lane_value(bk, 0);
+  b1 = lane_value(bk, 1);
+  b2 = lane_value(bk, 2);
+  const double ek = exp(pv);
+  double acc = lane_value(pv, 3), mine = acc;
+  for (int c = 2; c < C; ++c) {
+    acc += lane_value(ek, c + 2);
+    if (lane == c) mine = acc;
+  }
+  if (lane <= C) sb[lane] = lane == 0 ? -INFINITY : (lane == C ? INFINITY : mine);
 }
 
 template <int WPU>
@@ -312,23 +339,30 @@ __device__ inline double ll_param_pass(const double *__restrict__ f, const doubl
                                        double hh, int (*redi)[WPB], int &cp) {
   LogProduct prod;                       // pipelined like ll_f_pass, same early rejection
   prod.reset();
-  const int stride = 64 * WPU, iters = (n + stride - 1) / stride;
-  const int rc = min(row0, n - 1);
-  int yy = y[rc];
-  double fr = f[rc], xr = x[rc];
-  int r = row0;
-  for (int it = 0; it < iters; ++it, r += stride) {
-    const int rn = min(r + stride, n - 1);
-    const int yn = y[rn];
-    const double fn = f[rn], xn = x[rn];
+  const uint32_t stride = 64 * WPU, last = (uint32_t)(n - 1);
+  const int iters = (n + (int)stride - 1) / (int)stride;
+  auto cell = [&](int yy, double fr, double xr, uint32_t r) {
     const double gg = b0 + b1 * xr + b2 * xr * xr + fr;
     const int yc = max(yy, 1);
     const double p = ordinal_cell_prob(sb[yc - 1] - gg, sb[yc] - gg, sphi);
-    prod.mul(yy > 0 && r < n ? p : 1.0);
-    if ((it & (SLICE_CHECK - 1)) == SLICE_CHECK - 1 && it + 1 < iters && hh > -INFINITY &&
+    prod.mul(yy > 0 && r <= last ? p : 1.0);
+  };
+  uint32_t r = (uint32_t)row0;
+  const uint32_t r0 = min(r, last);
+  int ya = col_at(y, r0);
+  double fa = col_at(f, r0), xa = col_at(x, r0);
+  for (int it = 0; it < iters; it += 2, r += 2 * stride) {
+    const uint32_t r1 = min(r + stride, last);
+    const int yb = col_at(y, r1);
+    const double fb = col_at(f, r1), xb = col_at(x, r1);
+    cell(ya, fa, xa, r);
+    const uint32_t r2 = min(r + 2 * stride, last);
+    ya = col_at(y, r2);
+    fa = col_at(f, r2); xa = col_at(x, r2);
+    cell(yb, fb, xb, r + stride);
+    if ((it & (SLICE_CHECK - 1)) == SLICE_CHECK - 2 && it + 2 < iters && hh > -INFINITY &&
         surely_rejected<WPU>(prod.e, hh, redi[cp++ & 1], w))
       return -INFINITY;
-    yy = yn; fr = fn; xr = xn;
   }
   return unit_sum<WPU>(prod.log_value(), red, w);
 }
@@ -336,14 +370,14 @@ __device__ inline double ll_param_pass(const double *__restrict__ f, const doubl
 template <int WPU>
 __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
   __shared__ double sbb[WPB][MAXC + 2];
-  __shared__ double sphi[PHI_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
   __shared__ double red[WPB];
   __shared__ int redi[2][WPB];
   phi_table_to_lds(sphi);
   __syncthreads();
   int cp = 0;   // checks so far: consecutive checks alternate between the two exchange slots
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int u = WPU == 1 ? blockIdx.x * WPB + w : blockIdx.x;
+  const int u = WPU == 1 ? __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + w) : blockIdx.x;
   if (u >= a.U_pad || u % a.ML >= a.mloc) return;    // uniform over the workgroup when WPU = 4
   double *sb = sbb[WPU == 1 ? w : 0];
   const int row0 = WPU == 1 ? lane : lane + 64 * w;
@@ -352,24 +386,22 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
   const int8_t *y = a.y + a.ldy * u;
   const double *x = a.x + a.x_stride * (u / a.ML);
   const uint32_t ug = (uint32_t)((a.j0 + jl) + a.m * (u / a.ML));
-  double pm[3], ps[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { pm[k] = a.bpm[k + 3 * jl]; ps[k] = a.bps[k + 3 * jl]; }
 
-  double v[MAXD], nv[MAXD], pv[MAXD];
-  bool anyfree = false;
-#pragma unroll
-  for (int k = 0; k < MAXD; ++k) {
-    v[k] = 0.0; nv[k] = 0.0; pv[k] = 0.0;
-    if (k < D) {
-      bool is_free = k < 3 ? (ps[k] > 0.0) : !a.fixed_thr;
-      v[k] = k < 3 ? (is_free ? a.ebeta[k + 3 * u] : 0.0) : a.delta[(k - 3) + (int64_t)(C - 1) * u];
-      nv[k] = is_free ? rng_normal_at(a.seed, TAG_P_Z, a.sweep, ug, (uint32_t)k) : 0.0;
-      anyfree |= is_free;
-    }
-  }
+  // this lane's element of the vector: e[0..2] on lanes 0..2, delta[0..C-2] on lanes 3..C+1
+  const bool is_beta = lane < 3, mine = lane < D;
+  double pm_k = 0.0, ps_k = 0.0;
+  if (is_beta) { pm_k = a.bpm[lane + 3 * jl]; ps_k = a.bps[lane + 3 * jl]; }
+  const bool is_free = mine && (is_beta ? ps_k > 0.0 : !a.fixed_thr);
+  const bool rotates = is_beta || !a.fixed_thr;
+  double v = 0.0;
+  if (mine && !is_beta) v = a.delta[(lane - 3) + (int64_t)(C - 1) * u];
+  if (is_beta && is_free) v = a.ebeta[lane + 3 * u];
+  const double nv = is_free ? rng_normal_at(a.seed, TAG_P_Z, a.sweep, ug, (uint32_t)lane) : 0.0;
+  const bool anyfree = __any(is_free);
+  double pv = v;
+
   double b0, b1, b2;
-  params_from_white(v, pm, ps, C, b0, b1, b2, sb);
+  params_from_white(v, pm_k, ps_k, C, lane, b0, b1, b2, sb);
   if (WPU != 1) __syncthreads();          // the thresholds every wave just wrote (same values)
   // the slice update of f that ran just before left the log-likelihood of exactly this state
   const double cur = a.ll_in ? a.ll_in[u]
@@ -384,12 +416,9 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
     while (r < a.R) {
       double s, c;
       sincos(phi, &s, &c);
-#pragma unroll
-      for (int k = 0; k < MAXD; ++k) {
-        bool rot = k < 3 ? true : !a.fixed_thr;
-        pv[k] = rot ? v[k] * c + nv[k] * s : v[k];
-      }
-      params_from_white(pv, pm, ps, C, b0, b1, b2, sb);
+      pv = rotates ? v * c + nv * s : v;
+      // (every wave has left the last pass: its final sum, or the check that ended it, is a barrier)
+      params_from_white(pv, pm_k, ps_k, C, lane, b0, b1, b2, sb);
       if (WPU != 1) __syncthreads();
       l = ll_param_pass<WPU>(f, x, b0, b1, b2, y, sb, sphi, n, row0, red, w, hh, redi, cp);
       ++r;
@@ -401,29 +430,28 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
     }
   }
   if (!ok) {  // keep the current parameters
-    params_from_white(v, pm, ps, C, b0, b1, b2, sb);
+    params_from_white(v, pm_k, ps_k, C, lane, b0, b1, b2, sb);
     l = cur;
   }
   if (WPU != 1) __syncthreads();
-  const double *fin = ok ? pv : v;
-  if (lane == 0 && (WPU == 1 || w == 0)) {
-#pragma unroll
-    for (int k = 0; k < MAXD; ++k) {
-      if (k < 3) a.ebeta[k + 3 * u] = fin[k];
-      else if (k < D) a.delta[(k - 3) + (int64_t)(C - 1) * u] = fin[k];
+  const double fin = ok ? pv : v;
+  if (WPU == 1 || w == 0) {
+    if (is_beta) a.ebeta[lane + 3 * u] = fin;
+    else if (mine) a.delta[(lane - 3) + (int64_t)(C - 1) * u] = fin;
+    if (lane == 0) {
+      a.beta[3 * u] = b0; a.beta[3 * u + 1] = b1; a.beta[3 * u + 2] = b2;
+      a.betaS[u] = b0; a.betaS[u + a.U_pad] = b1; a.betaS[u + 2 * (int64_t)a.U_pad] = b2;
+      if (a.ll) a.ll[u] = l;
+      if (a.counters && anyfree) {
+        atomicAdd(&a.counters[0], (unsigned long long)(1 + r));
+        if (!ok) atomicAdd(&a.counters[1], 1ull);
+      }
     }
-    a.beta[3 * u] = b0; a.beta[3 * u + 1] = b1; a.beta[3 * u + 2] = b2;
-    a.betaS[u] = b0; a.betaS[u + a.U_pad] = b1; a.betaS[u + 2 * (int64_t)a.U_pad] = b2;
-    if (a.ll) a.ll[u] = l;
-    if (a.counters && anyfree) {
-      atomicAdd(&a.counters[0], (unsigned long long)(1 + r));
-      if (!ok) atomicAdd(&a.counters[1], 1ull);
+    if (lane <= C) {
+      double bv = sb[lane];
+      a.bthr[lane + (int64_t)(C + 1) * u] = bv;
+      a.bthrS[u + (int64_t)a.U_pad * lane] = bv;
     }
-  }
-  if (lane <= C && (WPU == 1 || w == 0)) {
-    double bv = sb[lane];
-    a.bthr[lane + (int64_t)(C + 1) * u] = bv;
-    a.bthrS[u + (int64_t)a.U_pad * lane] = bv;
   }
 }
 

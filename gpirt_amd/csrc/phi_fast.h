@@ -3,9 +3,11 @@
 // log( Phi(zhi) - Phi(zlo) )  (log_like_fn.m:3-4 with the probit link of sigmoid_fn.m:4,
 // ordinal form gpirt-sythetic.R:159-167) from two evaluations of the upper tail
 //   Phi(-z) = exp(-z^2/2) * g(z),  z >= 0,
-// where g is read from a 64-interval table of degree-6 polynomials (phi_table.h, relative
-// error <= 5e-16 on [0,40]).  No data-dependent branch: the library erfc picks one of
-// several code paths per lane, and a wave whose lanes straddle them pays for all.
+// where g is read from a table of degree-6 polynomials (phi_table.h, relative error <= 5e-16 on
+// [0,40]) whose interval number and local variable are cut out of the bits of z + 1: no
+// division (v_rcp_f64 alone costs as much as 3.4 fused multiply-adds, its Newton steps 4 more).
+// No data-dependent branch: the library erfc picks one of several code paths per lane, and a
+// wave whose lanes straddle them pays for all.
 #pragma once
 #include "common.h"
 
@@ -15,8 +17,9 @@
 namespace gpirt {
 
 constexpr int PHI_ROWS = GPIRT_PHI_K;
-constexpr int PHI_NC = GPIRT_PHI_DEG + 1;
-constexpr int PHI_LD = 9;   // LDS row stride (doubles): 72-byte rows spread the gathers over banks
+constexpr int PHI_NC = 6;        // doubles per row: c0..c4 and the two floats c5, c6 in the sixth
+constexpr int PHI_LD = PHI_NC;   // LDS row stride: 48-byte rows, three 16-byte reads, 16 bank positions
+constexpr int PHI_S = GPIRT_PHI_S;
 
 constexpr int EXP_TAB = 64;  // 2^(j/64), j = 0..63, behind the polynomial table
 constexpr int PHI_LDS_DOUBLES = PHI_ROWS * PHI_LD + EXP_TAB;
@@ -33,9 +36,8 @@ __device__ inline void phi_table_to_lds(double *s) {
 // 2^(j/64) from the table, exp(r) - 1 from a degree-5 polynomial (remainder 3e-17), scaled
 // by 2^m.  Branch-free; underflows gradually to zero.
 __device__ inline double exp_neg(double h, double l, const double *s) {
-  const double hc = fmax(h, -745.5);
-  const double nf = rint(hc * 92.33248261689366);              // 64 / ln 2
-  double r = fma(nf, -0.010830424695086549, hc);                // ln2/64 high part (33 bits: exact product)
+  const double nf = rint(h * 92.33248261689366);               // 64 / ln 2; h >= -800: fits an int with room
+  double r = fma(nf, -0.010830424695086549, h);                 // ln2/64 high part (33 bits: exact product)
   r = fma(nf, -1.162596423439437e-12, r) + l;                   // low part
   const int n = (int)nf;
   const double t = s[PHI_ROWS * PHI_LD + (n & (EXP_TAB - 1))];
@@ -48,21 +50,23 @@ __device__ inline double exp_neg(double h, double l, const double *s) {
 
 __device__ inline double phi_upper(double z, const double *s) {   // Phi(-z), z >= 0
   z = fmin(z, 40.0);                          // Phi(-40) is far below the smallest double
-  const double d = 1.0 + 0.5 * z;
-  double u = __builtin_amdgcn_rcp(d);
-  u = fma(u, fma(-d, u, 1.0), u);
-  u = fma(u, fma(-d, u, 1.0), u);
-  const double sc = u * (double)PHI_ROWS;
-  const int k = min((int)sc, PHI_ROWS - 1);
-  const double t = 2.0 * (sc - (double)k) - 1.0;
-  const double *c = s + k * PHI_LD;
-  double g = c[6];
-  g = fma(g, t, c[5]);
-  g = fma(g, t, c[4]);
-  g = fma(g, t, c[3]);
-  g = fma(g, t, c[2]);
-  g = fma(g, t, c[1]);
-  g = fma(g, t, c[0]);
+  const double w = z + 1.0;                   // in [1, 41]: exponent 0..5
+  const int hi = __double2hiint(w);
+  const int k = (hi >> (20 - PHI_S)) - (1023 << PHI_S);          // binade * 64 + top mantissa bits
+  // centre of the interval: the same high word with the lower mantissa bits replaced by 100..0
+  const double t = w - __hiloint2double((hi & ~((1 << (20 - PHI_S)) - 1)) | (1 << (19 - PHI_S)), 0);
+  int row = k * (PHI_LD * 8);
+  asm volatile("" : "+v"(row));               // one address, three immediate offsets
+  // 16-byte LDS reads move 256 bytes per clock, the 8-byte pairs (ds_read2_b64) half of that
+  const double2 *c = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s) + row);
+  const double2 c01 = c[0], c23 = c[1], c4p = c[2];
+  double g = (double)__int_as_float(__double2hiint(c4p.y));
+  g = fma(g, t, (double)__int_as_float(__double2loint(c4p.y)));
+  g = fma(g, t, c4p.x);
+  g = fma(g, t, c23.y);
+  g = fma(g, t, c23.x);
+  g = fma(g, t, c01.y);
+  g = fma(g, t, c01.x);
   const double h = -0.5 * z * z;
   const double l = fma(-0.5 * z, z, -h);      // rounding error of h, folded into the exponent
   return exp_neg(h, l, s) * g;

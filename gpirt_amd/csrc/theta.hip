@@ -64,7 +64,7 @@ int launch_theta_prepare(hipStream_t st, const ThetaArgs &a) {
 // round is the latency of one respondent's loop rather than the chip's throughput.
 template <int WPR>
 __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initial) {
-  __shared__ double sphi[PHI_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
   __shared__ double red[4];
   phi_table_to_lds(sphi);
   __syncthreads();
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initia
 // once per sweep (4 tails and 5 logs per grid point and unit instead of 2 tails per cell and
 // round) and a likelihood evaluation becomes a sum of gathered table entries.
 __global__ __launch_bounds__(256) void theta_table_kernel(ThetaArgs a) {
-  __shared__ double sphi[PHI_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
   phi_table_to_lds(sphi);
   __syncthreads();
   const int u = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
@@ -464,7 +464,7 @@ int launch_grid_onehot(hipStream_t st, const int8_t *yT, int n, int mloc, int ML
 
 // T[g + G_pad*(jl + ML*c)] = log-probability of category c+1 for item jl at grid point g
 __global__ __launch_bounds__(256) void grid_table_kernel(ThetaArgs a, int G_pad, double *__restrict__ T) {
-  __shared__ double sphi[PHI_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
   phi_table_to_lds(sphi);
   __syncthreads();
   const int g = blockIdx.x * blockDim.x + threadIdx.x, jl = blockIdx.y;
@@ -557,7 +557,7 @@ int launch_summary_theta(hipStream_t st, const double *theta, int64_t count, dou
 __global__ __launch_bounds__(256) void summary_prob_kernel(ThetaArgs a, int quadratic,
                                                            double *__restrict__ psum,
                                                            double *__restrict__ asum) {
-  __shared__ double sphi[PHI_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
   phi_table_to_lds(sphi);
   __syncthreads();
   const int u = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;

@@ -33,7 +33,7 @@ def main():
     if subs and subs[0].startswith("config:"):          # e.g. config:n=10000,m=4096
         config = {k: int(v) for k, v in (kv.split("=") for kv in subs[0][7:].split(","))}
         subs = subs[1:]
-    passes = {p: counters(os.path.join(base, p)) for p in ("fetch", "write", "sq", "sq2") if os.path.isdir(os.path.join(base, p))}
+    passes = {p: counters(os.path.join(base, p)) for p in ("fetch", "write", "sq", "sq2", "lds") if os.path.isdir(os.path.join(base, p))}
     dur = durations(os.path.join(base, "fetch"))
     report = {"how": "tools/pmc_collect.sh: one rocprofv3 --pmc run per pass (FETCH_SIZE | WRITE_SIZE | 8 SQ + GRBM | 8 SQ) of "
                      "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants` (8 sweeps with the set-up "
