@@ -334,7 +334,7 @@ def main():
         mloc = (cfg.item_end - cfg.item_begin) if world > 1 else m
         fl = dense_flops(n, mloc, cfg.n_grid)
         # Dominant kernel by device time: the FP64 MFMA GEMM.  Two of its instances carry the dense
-        # work of a sweep: the rank-512 trailing updates of the Cholesky (gemm_f64_kernel<false,true,1>,
+        # work of a sweep: the rank-512 trailing updates of the Cholesky (gemm_direct_kernel<true,1>,
         # ~19 launches per sweep, each bracketed by HIP events on the sampler's stream during the
         # timed region) and nu = L*Z (phase "nu": the one launch per sweep after the factorisation,
         # timed the same way; the rows computed beside the factorisation run as chunks on a second
@@ -342,11 +342,11 @@ def main():
         rec = pmc_record()
         nu_ms = phases["nu"]
         tiles = -(-n // 128) * -(-mloc // 128)
-        nu_kernel = ("gemm_f64_kernel<false,false,5> (nu = L*Z, rows %d..%d: one launch per sweep after the "
+        nu_kernel = ("gemm_direct_kernel<false,5> (nu = L*Z, rows %d..%d: one launch per sweep after the "
                      "factorisation; rows 0..%d run beside the factorisation on a second stream as "
-                     "gemm_f64_kernel<false,false,2>)" % (r0, n, r0) if r0 > 0 else
-                     "gemm_f64_kernel<false,false,4> (nu = L*Z, one launch per sweep)" if tiles >= 2048 else
-                     "gemm_f64_kernel<false,false,2> (nu = L*Z, one launch per sweep%s)"
+                     "gemm_direct_kernel<false,2>)" % (r0, n, r0) if r0 > 0 else
+                     "gemm_direct_kernel<false,4> (nu = L*Z, one launch per sweep)" if tiles >= 2048 else
+                     "gemm_direct_kernel<false,2> (nu = L*Z, one launch per sweep%s)"
                      % (", K in %d slabs + sum_slabs_kernel" % (8 if tiles < 512 else 4) if tiles < 1024 else ""))
         fl_launch = (float(n) * n - float(r0) * r0) * mloc      # triangular count of the rows r0..n
         nu_achieved = fl_launch / (nu_ms * 1e-3) / 1e12 if nu_ms > 0 else 0.0
@@ -377,7 +377,7 @@ def main():
                                       "stream-ordered" if native is not None else
                                       "gloo through host memory (rehearsal)" if rehearsal else "torch.distributed nccl")},
             "roofline": {
-                "kernel": "gemm_f64_kernel<false,true,1> (rank-512 trailing updates of the blocked Cholesky, lower "
+                "kernel": "gemm_direct_kernel<true,1> (rank-512 trailing updates of the blocked Cholesky, lower "
                           "tiles only): the kernel with the largest share of device time",
                 "bound": "mfma", "achieved": upd_achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": upd_achieved / FP64_MFMA_PEAK_TFLOPS,
@@ -411,7 +411,7 @@ def main():
             whole = float(n) * n * mloc / (nu_alone_ms * 1e-3) / 1e12
             wp = pmc_kernel(rec, "nu_whole", n, m, world)
             out["roofline"]["other_instances"]["nu_whole_product_in_one_launch"] = {
-                "kernel": "gemm_f64_kernel<false,false,4>, sweep 2 of the set-up (nothing beside the factorisation)",
+                "kernel": "gemm_direct_kernel<false,4>, sweep 2 of the set-up (nothing beside the factorisation)",
                 "ms_per_launch": nu_alone_ms, "flop_per_launch": float(n) * n * mloc,
                 "achieved": whole, "frac": whole / FP64_MFMA_PEAK_TFLOPS,
                 "algorithmic_bytes_per_launch": 8.0 * (float(n) * n / 2 + 2.0 * n * mloc),
@@ -435,7 +435,7 @@ def main():
             out["likelihood_kernels_measured"] = {
                 "source": "profiles/r02_pmc_kernels.json (rocprofv3 --pmc passes of this benchmark; durations and "
                           "rates are those under the profiler, which serialises kernels and lowers the clock)",
-                "bound": "FP64 VALU issue, not HBM: see valu_issue_cycles_share", "kernels": lik}
+                "bound": "FP64 VALU issue and LDS gathers of the Mills-ratio table, not HBM: see valu_issue_cycles_share", "kernels": lik}
         if variant is not None:
             out["variants"] = {"generator_prior": variant}
         if world == 1 and not args.no_cpu_baseline:

@@ -320,6 +320,167 @@ __global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs g, int nbn)
         C[(i0 + wm0 + ti * 16 + lr) + ldc * (int64_t)(j0 + wn0 + tj * 16 + lk + 4 * r)] = alpha * acc[tj][ti][r];
 }
 
+// ---------------------------------------------------------------------------------------
+// Register-fed variant for A(i,k) at A[i + lda*k] (the nu = L*Z products and the trailing updates
+// of the factorisation: all but a few per cent of the dense work).  No LDS image and no barrier in
+// the loop: every wave takes the fragments of its own 64x64 quadrant straight from global memory
+// (L1 / L2), in blocks of 8 k-values -- lane group lk holds k0 + 2 lk + {0, 1}, so that an operand
+// whose K index is contiguous comes in 16-byte loads and one whose tile index is contiguous in
+// 128-byte runs per 16 lanes -- and keeps the block being multiplied plus the next one in flight
+// (32 registers a block; a third block gained nothing).  The LDS version shares a slab among its four waves and pays a barrier per
+// 16 k-values, which two workgroups per CU do not fully cover (0.76 of the matrix peak on the
+// whole nu product); here nothing a wave waits for is owned by another wave (0.9 and more), at
+// twice the L2-to-CU traffic, which that path has room for.  All address arithmetic in the loop
+// is scalar: per-lane offsets are 32-bit and fixed, the block's base moves in scalar registers.
+// Tile order, modes, alpha / beta and the aliasing contract are those of gemm_f64_kernel.
+// ---------------------------------------------------------------------------------------
+constexpr int DKB = 8;       // k-values per block
+constexpr int DNBUF = 2;     // blocks of fragments held in registers; K is a multiple of DKB * DNBUF
+
+__device__ __forceinline__ double ld_f64(const double *base, uint32_t off) {
+  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + off);
+}
+__device__ __forceinline__ double2 ld_f64x2(const double *base, uint32_t off) {
+  return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + off);
+}
+
+template <bool BT, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs g, int nbm, int nbn) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = blockIdx.x, bi, bj;
+  if (MODE == 1) {
+    bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((int64_t)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    while ((int64_t)bi * (bi + 1) / 2 > t) --bi;
+    bj = t - (int)((int64_t)bi * (bi + 1) / 2);
+  } else if (MODE == 4) {   // XCD-aware order, see gemm_f64_kernel
+    const int x = t & 7, q = t >> 3;
+    const int sup = (q >> 5) * 8 + x, inner = q & 31;
+    const int nsj = (nbn + 3) / 4;
+    const int sbi = sup / nsj, sbj = sup % nsj;
+    bi = nbm - 1 - (sbi * 8 + (inner >> 2));
+    bj = sbj * 4 + (inner & 3);
+    if (bi < 0 || bj >= nbn) return;
+  } else if (MODE == 2 || MODE == 5) {   // longest K first
+    bi = nbm - 1 - t / nbn; bj = t % nbn;
+  } else {
+    bi = t / nbn; bj = t % nbn;
+  }
+  const int z = blockIdx.y;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int i0 = bi * TILE + (wave & 1) * 64, j0 = bj * TILE + (wave >> 1) * 64;   // this wave's quadrant
+  const int64_t lda = g.lda, ldb = g.ldb, ldc = g.ldc;
+  int kend = g.K;
+  if (MODE == 2 || MODE == 4 || MODE == 5) kend = min(g.K, (bi + 1) * TILE + g.k_base - z * g.k_shift);   // may be <= 0: a zero tile
+  const double alpha = g.alpha, beta = g.beta;
+  double *C = g.C + g.strideC * z;   // may alias A or B (in-place panel and solve steps)
+
+  v4d acc[4][4];
+  if (beta != 0.0) {
+    const double sc = beta / alpha;
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[tj][ti][r] = sc * C[(i0 + ti * 16 + lr) + ldc * (int64_t)(j0 + tj * 16 + lk + 4 * r)];
+  } else {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+
+  if (kend > 0) {   // uniform over the workgroup
+    // wave-uniform bases (scalar registers) and fixed per-lane byte offsets
+    const double *Aw = g.A + g.strideA * z + i0;
+    const double *Bw = g.B + g.strideB * z + (BT ? (int64_t)j0 : ldb * (int64_t)j0);
+    uint32_t oa[2], ob[BT ? 2 : 4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) oa[s] = (uint32_t)((lr + lda * (2 * lk + s)) * 8);
+    if (BT) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) ob[s] = (uint32_t)((lr + ldb * (2 * lk + s)) * 8);
+    } else {
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) ob[tj] = (uint32_t)((2 * lk + ldb * (16 * tj + lr)) * 8);
+    }
+    double fa[DNBUF][2][4];
+    double fb[DNBUF][2][4];      // [buffer][step][column tile]
+    const int nblk = kend / DKB;
+    auto load = [&](int buf, int blk) {
+      const int k0 = DKB * min(blk, nblk - 1);
+      const double *Ab = Aw + lda * (int64_t)k0;
+      const double *Bb = BT ? Bw + ldb * (int64_t)k0 : Bw + k0;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) fa[buf][s][ti] = ld_f64(Ab + 16 * ti, oa[s]);
+      if (BT) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int tj = 0; tj < 4; ++tj) fb[buf][s][tj] = ld_f64(Bb + 16 * tj, ob[s]);
+      } else {
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+          const double2 v = ld_f64x2(Bb, ob[tj]);
+          fb[buf][0][tj] = v.x;
+          fb[buf][1][tj] = v.y;
+        }
+      }
+    };
+#pragma unroll
+    for (int p = 0; p < DNBUF - 1; ++p) load(p, p);
+    for (int blk = 0; blk < nblk; blk += DNBUF) {
+#pragma unroll
+      for (int u = 0; u < DNBUF; ++u) {
+        load((u + DNBUF - 1) % DNBUF, blk + u + DNBUF - 1);
+        __builtin_amdgcn_sched_barrier(0);   // loads first: the next block stays in flight under the MFMAs
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti)
+              acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[u][s][tj], fa[u][s][ti], acc[tj][ti], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // C may be an operand of this very launch: no wave writes before every wave of the tile has read
+  __syncthreads();
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        C[(i0 + ti * 16 + lr) + ldc * (int64_t)(j0 + tj * 16 + lk + 4 * r)] = alpha * acc[tj][ti][r];
+}
+
+template <bool BT>
+static int launch_direct_mode(hipStream_t st, const GemmArgs &a, int mode, dim3 grid, int nbm, int nbn) {
+  dim3 block(256);
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((gemm_direct_kernel<BT, 0>), grid, block, 0, st, a, nbm, nbn); break;
+    case 1: hipLaunchKernelGGL((gemm_direct_kernel<BT, 1>), grid, block, 0, st, a, nbm, nbn); break;
+    case 2: hipLaunchKernelGGL((gemm_direct_kernel<BT, 2>), grid, block, 0, st, a, nbm, nbn); break;
+    case 4: hipLaunchKernelGGL((gemm_direct_kernel<BT, 4>), grid, block, 0, st, a, nbm, nbn); break;
+    default: hipLaunchKernelGGL((gemm_direct_kernel<BT, 5>), grid, block, 0, st, a, nbm, nbn); break;
+  }
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// GPIRT_GEMM_LDS=1 keeps every product on the LDS-staged kernel (for comparisons)
+static bool gemm_lds_only() {
+  static const bool v = getenv("GPIRT_GEMM_LDS") && atoi(getenv("GPIRT_GEMM_LDS")) != 0;
+  return v;
+}
+
 template <bool AT, bool BT>
 static int launch_gemm_mode(hipStream_t st, const GemmArgs &a, int mode, dim3 grid, int nbm, int nbn) {
   dim3 block(256);
@@ -371,6 +532,11 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
     return GPIRT_OK;
   }
   dim3 grid((unsigned)tiles, (unsigned)a.batch);
+  static_assert(BK % (DKB * DNBUF) == 0, "K granularity");
+  if (!AT && !gemm_lds_only() && a.k_base % BK == 0 && a.k_shift % BK == 0 && a.lda * 4 * 8 < (int64_t)1 << 31 && a.ldb * 80 * 8 < (int64_t)1 << 31) {
+    if (!BT && (mode == 0 || mode == 2 || mode == 4 || mode == 5)) return launch_direct_mode<false>(st, a, mode, grid, nbm, nbn);
+    if (BT && (mode == 0 || mode == 1)) return launch_direct_mode<true>(st, a, mode, grid, nbm, nbn);
+  }
   // only the combinations the sweep uses are instantiated
   if (!AT && !BT && (mode == 0 || mode == 2 || mode == 4 || mode == 5)) return launch_gemm_mode<false, false>(st, a, mode, grid, nbm, nbn);
   if (!AT && BT && (mode == 0 || mode == 1)) return launch_gemm_mode<false, true>(st, a, mode, grid, nbm, nbn);

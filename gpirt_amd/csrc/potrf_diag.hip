@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
   __shared__ __attribute__((aligned(16))) double T[TILE * XLD];
   __shared__ __attribute__((aligned(16))) double dinv[TILE];
   __shared__ __attribute__((aligned(16))) double ucol[2 * SB];
+  __builtin_amdgcn_s_setprio(3);          // critical path: ahead of any throughput wave on the same SIMD
   const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double *A = S + (int64_t)n_pad * n_pad * z + (int64_t)kb * TILE * (n_pad + 1);
@@ -363,6 +364,9 @@ __device__ __forceinline__ int trsm_at(int i, int k) { return k * SB + (i ^ ((k 
 __global__ __launch_bounds__(256) void trsm_panel_kernel(double *__restrict__ S, int n_pad, int kb,
                                                          const double *__restrict__ inv_diag) {
   __shared__ __attribute__((aligned(16))) double blk[TRSM_BLOCKS][SB * SB];
+  // on the factorisation's critical path, possibly on a SIMD shared with a wave of a throughput
+  // launch (the chunks of nu = L*Z on the second stream): issue first
+  __builtin_amdgcn_s_setprio(3);
   const int z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int row0 = (kb + 1) * TILE + 64 * blockIdx.x + 16 * wave;

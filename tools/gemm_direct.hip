@@ -1,0 +1,182 @@
+// Experiment: an FP64 MFMA GEMM whose waves take their operand fragments straight from global
+// memory (L1 / L2), no LDS image and no workgroup barrier.  C[M,N] = A[M,K] * B[K,N], all
+// column-major, M, N multiples of 128, K a multiple of 16.  One wave owns a 64 x 64 tile of C and
+// keeps NBUF blocks of 16 k-values of fragments in registers: the block being multiplied and
+// NBUF - 1 in flight.  Prints the rate and checks a sample of C against a host dot product.
+// Build: hipcc -O3 --offload-arch=gfx950 tools/gemm_direct.hip -o tools/gemm_direct
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// KB = 8: a block is 8 k-values, two MFMA steps; lane group lk holds k0 + 2 lk + {0, 1} of B in one
+// 16-byte load and the matching two values of A.  32 fragment registers per block.
+template <int NBUF, int WGS_PER_CU>
+__global__ __launch_bounds__(256, WGS_PER_CU) void gemm_direct8(const double *__restrict__ A, const double *__restrict__ B,
+                                                                double *__restrict__ C, int K, int64_t lda, int64_t ldb,
+                                                                int64_t ldc, int nbn, int group) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int t = blockIdx.x;
+  const int per = group * nbn, g0 = t / per, in = t % per;
+  const int bi = g0 * group + in % group, bj = in / group;
+  const int i0 = bi * 128 + (wave & 1) * 64, j0 = bj * 128 + (wave >> 1) * 64;
+  const double *Ap = A + (i0 + lr) + lda * (int64_t)(2 * lk);
+  const double *Bp = B + (2 * lk) + ldb * (int64_t)(j0 + lr);
+  v4d acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double fa[NBUF][2][4];
+  double2 fb[NBUF][4];
+  const int nblk = K / 8;
+  auto load = [&](int buf, int blk) {
+    const int k0 = 8 * (blk < nblk ? blk : nblk - 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) fa[buf][s][ti] = Ap[16 * ti + lda * (int64_t)(k0 + s)];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+      fb[buf][tj] = *reinterpret_cast<const double2 *>(Bp + ldb * (int64_t)(16 * tj) + k0);
+  };
+#pragma unroll
+  for (int p = 0; p < NBUF - 1; ++p) load(p, p);
+  for (int blk = 0; blk < nblk; blk += NBUF) {
+#pragma unroll
+    for (int u = 0; u < NBUF; ++u) {
+      load((u + NBUF - 1) % NBUF, blk + u + NBUF - 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+          const double bv = s ? fb[u][tj].y : fb[u][tj].x;
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti)
+            acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, fa[u][s][ti], acc[tj][ti], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        C[(i0 + ti * 16 + lr) + ldc * (int64_t)(j0 + tj * 16 + lk + 4 * r)] = acc[tj][ti][r];
+}
+
+template <int NBUF, int WGS_PER_CU>
+__global__ __launch_bounds__(256, WGS_PER_CU) void gemm_direct(const double *__restrict__ A, const double *__restrict__ B,
+                                                               double *__restrict__ C, int K, int64_t lda, int64_t ldb,
+                                                               int64_t ldc, int nbn, int group) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  // tiles in groups of `group` row blocks: the workgroups running together share few panels
+  const int t = blockIdx.x;
+  const int per = group * nbn, g0 = t / per, in = t % per;
+  const int bi = g0 * group + in % group, bj = in / group;
+  const int i0 = bi * 128 + (wave & 1) * 64, j0 = bj * 128 + (wave >> 1) * 64;
+  const double *Ap = A + (i0 + lr) + lda * (int64_t)(4 * lk);
+  const double *Bp = B + (4 * lk) + ldb * (int64_t)(j0 + lr);
+  v4d acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double fa[NBUF][4][4];       // [buffer][step s][row tile]: A[i][k0 + 4 lk + s]
+  double2 fb[NBUF][4][2];      // [buffer][col tile][half]:  B[k0 + 4 lk + 2 half + {0,1}][j]
+  const int nblk = K / 16;
+  auto load = [&](int buf, int blk) {
+    const int k0 = 16 * (blk < nblk ? blk : nblk - 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) fa[buf][s][ti] = Ap[16 * ti + lda * (int64_t)(k0 + s)];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        fb[buf][tj][h] = *reinterpret_cast<const double2 *>(Bp + ldb * (int64_t)(16 * tj) + k0 + 2 * h);
+  };
+#pragma unroll
+  for (int p = 0; p < NBUF - 1; ++p) load(p, p);
+  for (int blk = 0; blk < nblk; blk += NBUF) {
+#pragma unroll
+    for (int u = 0; u < NBUF; ++u) {
+      load((u + NBUF - 1) % NBUF, blk + u + NBUF - 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+          const double bv = (s & 1) ? fb[u][tj][s >> 1].y : fb[u][tj][s >> 1].x;
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti)
+            acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, fa[u][s][ti], acc[tj][ti], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        C[(i0 + ti * 16 + lr) + ldc * (int64_t)(j0 + tj * 16 + lk + 4 * r)] = acc[tj][ti][r];
+}
+
+int main(int argc, char **argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 10112, N = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 4800;
+  const int variant = argc > 4 ? atoi(argv[4]) : 0, group = argc > 5 ? atoi(argv[5]) : 8;
+  if (M % 128 || N % 128 || K % 48 || (M / 128) % group) { printf("need M, N multiples of 128, K of 48, M/128 of the group\n"); return 1; }
+  std::vector<double> hA((size_t)M * K), hB((size_t)K * N);
+  unsigned s = 12345;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (double)(s >> 8) / (1 << 24) - 0.5; };
+  for (auto &v : hA) v = rnd();
+  for (auto &v : hB) v = rnd();
+  double *A, *B, *C;
+  CK(hipMalloc(&A, sizeof(double) * hA.size())); CK(hipMalloc(&B, sizeof(double) * hB.size()));
+  CK(hipMalloc(&C, sizeof(double) * (size_t)M * N));
+  CK(hipMemcpy(A, hA.data(), sizeof(double) * hA.size(), hipMemcpyHostToDevice));
+  CK(hipMemcpy(B, hB.data(), sizeof(double) * hB.size(), hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int nbn = N / 128, grid = (M / 128) * nbn;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipEventRecord(e0, 0));
+    if (variant == 0) hipLaunchKernelGGL((gemm_direct<3, 1>), dim3(grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group);
+    if (variant == 1) hipLaunchKernelGGL((gemm_direct<2, 1>), dim3(grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group);
+    if (variant == 3) hipLaunchKernelGGL((gemm_direct8<3, 2>), dim3(grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group);
+    if (variant == 4) hipLaunchKernelGGL((gemm_direct8<2, 2>), dim3(grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group);
+    if (variant == 5) hipLaunchKernelGGL((gemm_direct8<4, 1>), dim3(grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group);
+    if (variant == 2) hipLaunchKernelGGL((gemm_direct<2, 2>), dim3(grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group);
+    CK(hipGetLastError());
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("variant %d group %d  M %d N %d K %d  %.3f ms  %.1f TFLOP/s\n", variant, group, M, N, K, ms, 2.0 * M * N * K / ms * 1e-9);
+  }
+  std::vector<double> hC((size_t)M * N);
+  CK(hipMemcpy(hC.data(), C, sizeof(double) * hC.size(), hipMemcpyDeviceToHost));
+  double worst = 0;
+  for (int q = 0; q < 200; ++q) {
+    s = s * 1664525u + 1013904223u; const int i = (s >> 8) % M;
+    s = s * 1664525u + 1013904223u; const int j = (s >> 8) % N;
+    double ref = 0;
+    for (int k = 0; k < K; ++k) ref += hA[i + (size_t)M * k] * hB[k + (size_t)K * j];
+    worst = fmax(worst, fabs(ref - hC[i + (size_t)M * j]));
+  }
+  printf("max abs error over 200 sampled entries: %.3e\n", worst);
+  return worst < 1e-9 ? 0 : 2;
+}
