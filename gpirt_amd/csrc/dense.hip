@@ -326,8 +326,8 @@ __global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs g, int nbn)
 // the loop: every wave takes the fragments of its own 64x64 quadrant straight from global memory
 // (L1 / L2), in blocks of 8 k-values -- lane group lk holds k0 + 2 lk + {0, 1}, so that an operand
 // whose K index is contiguous comes in 16-byte loads and one whose tile index is contiguous in
-// 128-byte runs per 16 lanes -- and keeps the block being multiplied plus the next one in flight
-// (32 registers a block; a third block gained nothing).  The LDS version shares a slab among its four waves and pays a barrier per
+// 128-byte runs per 16 lanes -- and keeps the block being multiplied plus the next two in flight
+// (32 registers a block; the third block is worth 2 % in the sweep, nothing in a warm loop).  The LDS version shares a slab among its four waves and pays a barrier per
 // 16 k-values, which two workgroups per CU do not fully cover (0.76 of the matrix peak on the
 // whole nu product); here nothing a wave waits for is owned by another wave (0.9 and more), at
 // twice the L2-to-CU traffic, which that path has room for.  All address arithmetic in the loop
@@ -335,7 +335,10 @@ __global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs g, int nbn)
 // Tile order, modes, alpha / beta and the aliasing contract are those of gemm_f64_kernel.
 // ---------------------------------------------------------------------------------------
 constexpr int DKB = 8;       // k-values per block
-constexpr int DNBUF = 2;     // blocks of fragments held in registers; K is a multiple of DKB * DNBUF
+#ifndef GPIRT_DNBUF
+#define GPIRT_DNBUF 3
+#endif
+constexpr int DNBUF = GPIRT_DNBUF;   // blocks of fragments held in registers
 
 __device__ __forceinline__ double ld_f64(const double *base, uint32_t off) {
   return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + off);
@@ -434,21 +437,29 @@ __global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs g, int nbm
     };
 #pragma unroll
     for (int p = 0; p < DNBUF - 1; ++p) load(p, p);
-    for (int blk = 0; blk < nblk; blk += DNBUF) {
+    auto mfma_block = [&](int u) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti)
+            acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[u][s][tj], fa[u][s][ti], acc[tj][ti], 0, 0, 0);
+    };
+    const int nmain = nblk / DNBUF * DNBUF;
+    for (int blk = 0; blk < nmain; blk += DNBUF) {
 #pragma unroll
       for (int u = 0; u < DNBUF; ++u) {
         load((u + DNBUF - 1) % DNBUF, blk + u + DNBUF - 1);
-        __builtin_amdgcn_sched_barrier(0);   // loads first: the next block stays in flight under the MFMAs
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-            for (int ti = 0; ti < 4; ++ti)
-              acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[u][s][tj], fa[u][s][ti], acc[tj][ti], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // loads first: the next blocks stay in flight under the MFMAs
+        mfma_block(u);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    // the blocks left over (fewer than DNBUF) are in the buffers already, in order from buffer 0
+#pragma unroll
+    for (int u = 0; u < DNBUF - 1; ++u)
+      if (nmain + u < nblk) mfma_block(u);
   }
   // C may be an operand of this very launch: no wave writes before every wave of the tile has read
   __syncthreads();
@@ -532,7 +543,7 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
     return GPIRT_OK;
   }
   dim3 grid((unsigned)tiles, (unsigned)a.batch);
-  static_assert(BK % (DKB * DNBUF) == 0, "K granularity");
+  static_assert(BK % DKB == 0, "K granularity");
   if (!AT && !gemm_lds_only() && a.k_base % BK == 0 && a.k_shift % BK == 0 && a.lda * 4 * 8 < (int64_t)1 << 31 && a.ldb * 80 * 8 < (int64_t)1 << 31) {
     if (!BT && (mode == 0 || mode == 2 || mode == 4 || mode == 5)) return launch_direct_mode<false>(st, a, mode, grid, nbm, nbn);
     if (BT && (mode == 0 || mode == 1)) return launch_direct_mode<true>(st, a, mode, grid, nbm, nbn);

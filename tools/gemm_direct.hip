@@ -19,12 +19,26 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 template <int NBUF, int WGS_PER_CU>
 __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_direct8(const double *__restrict__ A, const double *__restrict__ B,
                                                                 double *__restrict__ C, int K, int64_t lda, int64_t ldb,
-                                                                int64_t ldc, int nbn, int group) {
+                                                                int64_t ldc, int nbn, int group, int nbm, int order, int tri) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int t = blockIdx.x;
-  const int per = group * nbn, g0 = t / per, in = t % per;
-  const int bi = g0 * group + in % group, bj = in / group;
+  int bi, bj;
+  if (order == 0) {
+    const int per = group * nbn, g0 = t / per, in = t % per;
+    bi = g0 * group + in % group; bj = in / group;
+  } else if (order == 1) {            // longest K first, row-major
+    bi = nbm - 1 - t / nbn; bj = t % nbn;
+  } else {                            // 8 x 4 super-tiles per XCD share, longest K first
+    const int x = t & 7, q = t >> 3;
+    const int sup = (q >> 5) * 8 + x, inner = q & 31;
+    const int nsj = (nbn + 3) / 4;
+    const int sbi = sup / nsj, sbj = sup % nsj;
+    bi = nbm - 1 - (sbi * 8 + (inner >> 2));
+    bj = sbj * 4 + (inner & 3);
+    if (bi < 0 || bj >= nbn) return;
+  }
+  if (tri) K = min(K, (bi + 1) * 128);
   const int i0 = bi * 128 + (wave & 1) * 64, j0 = bj * 128 + (wave >> 1) * 64;
   const double *Ap = A + (i0 + lr) + lda * (int64_t)(2 * lk);
   const double *Bp = B + (2 * lk) + ldb * (int64_t)(j0 + lr);
@@ -135,9 +149,21 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_direct(const double *__r
         C[(i0 + ti * 16 + lr) + ldc * (int64_t)(j0 + tj * 16 + lk + 4 * r)] = acc[tj][ti][r];
 }
 
+// one workgroup that keeps one CU busy for about `clocks` cycles: a stand-in for the factorisation's
+// chain of one-workgroup kernels, during which the rest of the chip idles
+__global__ void spin_kernel(long long clocks, double *out) {
+  const long long t0 = __builtin_readcyclecounter();
+  double v = threadIdx.x;
+  while ((long long)__builtin_readcyclecounter() - t0 < clocks) v = v * 1.0000001 + 1e-9;
+  if (v == 12345.678) out[0] = v;
+}
+
 int main(int argc, char **argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 10112, N = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 4800;
   const int variant = argc > 4 ? atoi(argv[4]) : 0, group = argc > 5 ? atoi(argv[5]) : 8;
+  const int flush = argc > 6 ? atoi(argv[6]) : 0;      // 1: sweep a 2 GB buffer between launches (cold caches)
+  const int order = argc > 7 ? atoi(argv[7]) : 0, tri = argc > 8 ? atoi(argv[8]) : 0;
+  const int chain = argc > 9 ? atoi(argv[9]) : 0;      // tiny one-workgroup kernels before every launch (count)
   if (M % 128 || N % 128 || K % 48 || (M / 128) % group) { printf("need M, N multiples of 128, K of 48, M/128 of the group\n"); return 1; }
   std::vector<double> hA((size_t)M * K), hB((size_t)K * N);
   unsigned s = 12345;
@@ -152,20 +178,26 @@ int main(int argc, char **argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int nbn = N / 128, grid = (M / 128) * nbn;
-  for (int rep = 0; rep < 4; ++rep) {
+  char *scratch = nullptr;
+  if (flush) CK(hipMalloc(&scratch, (size_t)2 << 30));
+  for (int rep = 0; rep < 6; ++rep) {
+    if (flush) CK(hipMemsetAsync(scratch, rep, (size_t)2 << 30, 0));
+    for (int q = 0; q < chain; ++q) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(256), 0, 0, 60000LL, C);
     CK(hipEventRecord(e0, 0));
     if (variant == 0) hipLaunchKernelGGL((gemm_direct<3, 1>), dim3(grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group);
     if (variant == 1) hipLaunchKernelGGL((gemm_direct<2, 1>), dim3(grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group);
-    if (variant == 3) hipLaunchKernelGGL((gemm_direct8<3, 2>), dim3(grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group);
-    if (variant == 4) hipLaunchKernelGGL((gemm_direct8<2, 2>), dim3(grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group);
-    if (variant == 5) hipLaunchKernelGGL((gemm_direct8<4, 1>), dim3(grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group);
+    if (variant == 3) hipLaunchKernelGGL((gemm_direct8<3, 2>), dim3(grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group, M / 128, order, tri);
+    if (variant == 4) hipLaunchKernelGGL((gemm_direct8<2, 2>), dim3(order == 2 ? ((M / 128 + 7) / 8 * ((nbn + 3) / 4) + 7) / 8 * 8 * 32 : grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group, M / 128, order, tri);
+    if (variant == 5) hipLaunchKernelGGL((gemm_direct8<4, 1>), dim3(grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group, M / 128, order, tri);
     if (variant == 2) hipLaunchKernelGGL((gemm_direct<2, 2>), dim3(grid), dim3(256), 0, 0, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, nbn, group);
     CK(hipGetLastError());
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("variant %d group %d  M %d N %d K %d  %.3f ms  %.1f TFLOP/s\n", variant, group, M, N, K, ms, 2.0 * M * N * K / ms * 1e-9);
+    double flop = 2.0 * M * N * K;
+    if (tri) { flop = 0; for (int b = 0; b < M / 128; ++b) flop += 2.0 * 128 * N * (double)((b + 1) * 128 < K ? (b + 1) * 128 : K); }
+    printf("variant %d group %d order %d tri %d  M %d N %d K %d  %.3f ms  %.1f TFLOP/s\n", variant, group, order, tri, M, N, K, ms, flop / ms * 1e-9);
   }
   std::vector<double> hC((size_t)M * N);
   CK(hipMemcpy(hC.data(), C, sizeof(double) * hC.size(), hipMemcpyDeviceToHost));
@@ -174,7 +206,7 @@ int main(int argc, char **argv) {
     s = s * 1664525u + 1013904223u; const int i = (s >> 8) % M;
     s = s * 1664525u + 1013904223u; const int j = (s >> 8) % N;
     double ref = 0;
-    for (int k = 0; k < K; ++k) ref += hA[i + (size_t)M * k] * hB[k + (size_t)K * j];
+    for (int k = 0; k < (tri ? ((i / 128 + 1) * 128 < K ? (i / 128 + 1) * 128 : K) : K); ++k) ref += hA[i + (size_t)M * k] * hB[k + (size_t)K * j];
     worst = fmax(worst, fabs(ref - hC[i + (size_t)M * j]));
   }
   printf("max abs error over 200 sampled entries: %.3e\n", worst);
