@@ -35,7 +35,7 @@ def main():
         subs = subs[1:]
     passes = {p: counters(os.path.join(base, p)) for p in ("fetch", "write", "sq", "sq2", "lds") if os.path.isdir(os.path.join(base, p))}
     dur = durations(os.path.join(base, "fetch"))
-    report = {"how": "tools/pmc_collect.sh: one rocprofv3 --pmc run per pass (FETCH_SIZE | WRITE_SIZE | 8 SQ + GRBM | 8 SQ) of "
+    report = {"how": "tools/pmc_collect.sh: one rocprofv3 --pmc run per pass (FETCH_SIZE | WRITE_SIZE | 8 SQ + GRBM | 8 SQ | LDS array + VALU + GRBM) of "
                      "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants` (8 sweeps with the set-up "
                      "sweeps); means per launch; durations are those of the FETCH_SIZE pass (counter collection "
                      "serialises kernels and lowers the clock: compare with the un-profiled kernel_stats)",
@@ -66,6 +66,12 @@ def main():
             row["valu_insts_per_wave"] = row["SQ_INSTS_VALU"] / row["SQ_WAVES"]
         if "SQ_ACTIVE_INST_VALU" in row and row.get("SQ_WAVE_CYCLES"):
             row["valu_active_share_of_wave_cycles"] = row["SQ_ACTIVE_INST_VALU"] / row["SQ_WAVE_CYCLES"]
+        if row.get("SQ_LDS_IDX_ACTIVE") and row.get("GRBM_GUI_ACTIVE"):
+            cyc = row["GRBM_GUI_ACTIVE"] / 8.0                       # summed over the 8 XCDs
+            row["lds_array_busy_share"] = row["SQ_LDS_IDX_ACTIVE"] / 256.0 / cyc          # per CU
+            row["lds_bank_conflict_share_of_lds_cycles"] = row.get("SQ_LDS_BANK_CONFLICT", 0.0) / row["SQ_LDS_IDX_ACTIVE"]
+            if row.get("SQ_ACTIVE_INST_VALU"):
+                row["valu_busy_share"] = row["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc  # per SIMD, 4 clocks a unit
         report["kernels"][label or sub] = row
     json.dump(report, open(dest, "w"), indent=1)
     print(json.dumps(report, indent=1))
