@@ -568,6 +568,9 @@ __global__ void k_build_kernel(const double *__restrict__ x, int64_t x_stride, i
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y;
   if (i >= n_pad) return;
+  // the lower form leaves the tiles wholly above the diagonal alone: nothing reads them (the
+  // factorisation and the products with the factor touch tiles on and below the diagonal only)
+  if (!full && i < (j & ~(TILE - 1))) return;
   double v;
   if (i < n && j < n) {
     if (i >= j || full) {
