@@ -472,6 +472,109 @@ __global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs g, int nbm
         C[(i0 + ti * 16 + lr) + ldc * (int64_t)(j0 + tj * 16 + lk + 4 * r)] = alpha * acc[tj][ti][r];
 }
 
+// The register-fed loop on 64x64 tiles for the products with few tiles and a short K (the in-panel
+// updates of the factorisation, K = 128; its last, small trailing updates, K = 512): a wave owns a
+// 32x32 quadrant (2x2 MFMA tiles), nothing is staged, nothing is waited for but the wave's own loads,
+// and with ~100 registers a thread every workgroup of such a launch is resident at once.
+template <bool BT>
+__global__ __launch_bounds__(256) void gemm_direct_small_kernel(GemmArgs g, int nbn) {
+  __builtin_amdgcn_s_setprio(3);   // critical path of the factorisation, see gemm_small_kernel
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bi = blockIdx.x / nbn, bj = blockIdx.x % nbn, z = blockIdx.y;
+  if (g.lower_only && bi < bj) return;   // C square: 64 x 64 tiles wholly above the diagonal are not wanted
+  const int lr = lane & 15, lk = lane >> 4;
+  const int i0 = bi * 64 + (wave & 1) * 32, j0 = bj * 64 + (wave >> 1) * 32;
+  const int64_t lda = g.lda, ldb = g.ldb, ldc = g.ldc;
+  const double alpha = g.alpha, beta = g.beta;
+  double *C = g.C + g.strideC * z;
+  v4d acc[2][2];
+  if (beta != 0.0) {
+    const double sc = beta / alpha;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[tj][ti][r] = sc * C[(i0 + ti * 16 + lr) + ldc * (int64_t)(j0 + tj * 16 + lk + 4 * r)];
+  } else {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+  const double *Aw = g.A + g.strideA * z + i0;
+  const double *Bw = g.B + g.strideB * z + (BT ? (int64_t)j0 : ldb * (int64_t)j0);
+  uint32_t oa[2], ob[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) oa[s] = (uint32_t)((lr + lda * (2 * lk + s)) * 8);
+  if (BT) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) ob[s] = (uint32_t)((lr + ldb * (2 * lk + s)) * 8);
+  } else {
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) ob[tj] = (uint32_t)((2 * lk + ldb * (16 * tj + lr)) * 8);
+  }
+  constexpr int NB = 4;
+  double fa[NB][2][2], fb[NB][2][2];
+  const int nblk = g.K / DKB;
+  auto load = [&](int buf, int blk) {
+    const int k0 = DKB * min(blk, nblk - 1);
+    const double *Ab = Aw + lda * (int64_t)k0;
+    const double *Bb = BT ? Bw + ldb * (int64_t)k0 : Bw + k0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) fa[buf][s][ti] = ld_f64(Ab + 16 * ti, oa[s]);
+    if (BT) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) fb[buf][s][tj] = ld_f64(Bb + 16 * tj, ob[s]);
+    } else {
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        const double2 v = ld_f64x2(Bb, ob[tj]);
+        fb[buf][0][tj] = v.x;
+        fb[buf][1][tj] = v.y;
+      }
+    }
+  };
+  auto mfma_block = [&](int u) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+          acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[u][s][tj], fa[u][s][ti], acc[tj][ti], 0, 0, 0);
+  };
+#pragma unroll
+  for (int p = 0; p < NB - 1; ++p) load(p, p);
+  const int nmain = nblk / NB * NB;
+  for (int blk = 0; blk < nmain; blk += NB) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      load((u + NB - 1) % NB, blk + u + NB - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NB - 1; ++u)
+    if (nmain + u < nblk) mfma_block(u);
+  __syncthreads();   // C may be an operand of this launch
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        C[(i0 + ti * 16 + lr) + ldc * (int64_t)(j0 + tj * 16 + lk + 4 * r)] = alpha * acc[tj][ti][r];
+}
+
 template <bool BT>
 static int launch_direct_mode(hipStream_t st, const GemmArgs &a, int mode, dim3 grid, int nbm, int nbn) {
   dim3 block(256);
@@ -535,7 +638,11 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
       (mode == 1 && !AT && BT && tiles * a.batch <= small_lower && a.K % SK == 0 && a.K <= 512)) {
     if (mode == 1) tiles = (int64_t)nbm * nbn;      // the grid covers the square; tiles above the diagonal exit
     dim3 sgrid((unsigned)(4 * tiles), (unsigned)a.batch), block(256);
-    if (!AT && BT) hipLaunchKernelGGL((gemm_small_kernel<false, true>), sgrid, block, 0, st, a, 2 * nbn);
+    static const bool small_direct = !(getenv("GPIRT_SMALL_DIRECT") && atoi(getenv("GPIRT_SMALL_DIRECT")) == 0);
+    const bool direct_ok = small_direct && !gemm_lds_only() && a.lda * 4 * 8 < (int64_t)1 << 31 && a.ldb * 80 * 8 < (int64_t)1 << 31;
+    if (!AT && BT && direct_ok) hipLaunchKernelGGL((gemm_direct_small_kernel<true>), sgrid, block, 0, st, a, 2 * nbn);
+    else if (!AT && !BT && direct_ok) hipLaunchKernelGGL((gemm_direct_small_kernel<false>), sgrid, block, 0, st, a, 2 * nbn);
+    else if (!AT && BT) hipLaunchKernelGGL((gemm_small_kernel<false, true>), sgrid, block, 0, st, a, 2 * nbn);
     else if (!AT && !BT) hipLaunchKernelGGL((gemm_small_kernel<false, false>), sgrid, block, 0, st, a, 2 * nbn);
     else if (AT && !BT) hipLaunchKernelGGL((gemm_small_kernel<true, false>), sgrid, block, 0, st, a, 2 * nbn);
     else { set_error("launch_gemm: A^T B^T is not built"); return GPIRT_ERR_BAD_ARG; }
