@@ -21,12 +21,13 @@ __device__ __forceinline__ v4d mfma4(double a, double b, v4d c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// 1/sqrt(d): hardware estimate plus two Newton steps
+// 1/sqrt(d): hardware estimate (relative error 2^-24, tools/rsq_err.hip) plus ONE third-order
+// step: with e = 1 - d y^2, 1/sqrt(d) = y (1 + e/2 + 3 e^2/8 + O(e^3)), remainder 2^-70.  Four
+// dependent operations where two Newton steps are eight: this sits in the pivot loop's chain.
 __device__ __forceinline__ double rsqrt_nr(double d) {
-  double y = __builtin_amdgcn_rsq(d);
-  y = y * (1.5 - 0.5 * d * y * y);
-  y = y * (1.5 - 0.5 * d * y * y);
-  return y;
+  const double y = __builtin_amdgcn_rsq(d);
+  const double e = fma(-(d * y), y, 1.0);
+  return fma(y * e, fma(e, 0.375, 0.5), y);
 }
 
 // The inverse X = L^-1 is kept transposed in the strict upper triangle of the same LDS image
