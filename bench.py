@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
 
 One step = one Gibbs sweep (main.m:46-87 body) over the whole synthetic response matrix of
-BASELINE.json's scale-out configuration: n = 10 000 respondents, m = 4096 items, C = 5
+the scale-out configuration: n = 10 000 respondents, m = 4096 items, C = 5
 ordinal categories, H = 1.  With N > 1 the items are sharded over the ranks (one process per
 GPU, `python -m torch.distributed.run ...`), the total work is fixed (strong scaling) and the
 respondent step exchanges one n-vector all-reduce per proposal round over RCCL.

@@ -4,7 +4,7 @@
  * never load RCCL).  No torch, no MPI: the host only has to carry 128 bytes from rank 0 to
  * the other ranks once.
  *
- * The reference has no counterpart (it is single-process R, SURVEY of its files finds no
+ * The reference has no counterpart (it is single-process R and holds no
  * collective anywhere); what this serves is gpirt_config.allreduce of include/gpirt.h, the
  * one exchange of the sharded sweep: per lock-step proposal round of the respondent step
  * (utils/sample_score.m's role in main.m:63), the sum over ranks of each rank's per-respondent

@@ -1,4 +1,4 @@
-"""BASELINE configuration D on the device: the TAPS economic panel (251 panelists x 6
+"""The TAPS configuration on the device: the TAPS economic panel (251 panelists x 6
 questions x 41 waves, C = 5, a third of the cells missing) with one response function per item
 shared by all waves (`constant_IRF = 1`: every (panelist, wave) pair is an input of the item's
 GP, 10 291 of them) and exactly the arguments of TAPS/gpirt_TAPS.R:17-36 --

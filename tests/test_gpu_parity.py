@@ -334,7 +334,7 @@ def test_device_summaries_match_the_kept_draws(const, quad):
 
 
 def test_config_c_senate_116_recovers_the_nominate_ordering():
-    """BASELINE config C end to end: the 116th Senate roll-call cube (103 x 703, binary,
+    """The Senate configuration end to end: the 116th Senate roll-call cube (103 x 703, binary,
     built by gpirt_amd.builders.senate_cube) through the gpirtMCMC mirror from a random start;
     the posterior mean of theta must order the senators like NOMINATE's first dimension
     (the comparison of gpirt-senate.R:86-127)."""

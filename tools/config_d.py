@@ -1,4 +1,4 @@
-"""BASELINE config D on one GPU: the TAPS panel (251 panelists x 6 items x 41 waves) with one
+"""The TAPS configuration on one GPU: the panel (251 panelists x 6 items x 41 waves) with one
 response function per item shared by all waves (constant_IRF = 1: 10 291 stacked inputs), the
 settings of TAPS/gpirt_TAPS.R:17-36.  Prints time per sweep and the phase split."""
 import os, sys, time
