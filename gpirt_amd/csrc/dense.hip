@@ -666,31 +666,39 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
 // ---------------------------------------------------------------------------------------
 // Kernel-matrix build (a1) and the grid cross-covariance K(x, xs) used by f* (a6)
 // ---------------------------------------------------------------------------------------
+constexpr int KB_COLS = 8;   // columns per thread: the row's input is loaded once, the grid is 8x smaller
+
 __global__ void k_build_kernel(const double *__restrict__ x, int64_t x_stride, int n, int n_pad,
                                double inv_ls2, double sf2, double jitter, double *__restrict__ S,
                                int full) {
   const int z = blockIdx.z;
   const double *xp = x + x_stride * z;
   double *Sp = S + (int64_t)n_pad * n_pad * z;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int j = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j0 = blockIdx.y * KB_COLS;          // KB_COLS divides TILE: the columns share a tile column
   if (i >= n_pad) return;
   // the lower form leaves the tiles wholly above the diagonal alone: nothing reads them (the
   // factorisation and the products with the factor touch tiles on and below the diagonal only)
-  if (!full && i < (j & ~(TILE - 1))) return;
-  double v;
-  if (i < n && j < n) {
-    if (i >= j || full) {
-      double d = xp[i] - xp[j];
-      v = sf2 * exp(-0.5 * d * d * inv_ls2) + (i == j ? jitter : 0.0);
-    } else v = 0.0;
-  } else v = (i == j) ? 1.0 : 0.0;
-  Sp[i + (int64_t)n_pad * j] = v;
+  if (!full && i < (j0 & ~(TILE - 1))) return;
+  const double xi = i < n ? xp[i] : 0.0;
+#pragma unroll
+  for (int q = 0; q < KB_COLS; ++q) {
+    const int j = j0 + q;
+    double v;
+    if (i < n && j < n) {
+      if (i >= j || full) {
+        double d = xi - xp[j];
+        v = sf2 * exp(-0.5 * d * d * inv_ls2) + (i == j ? jitter : 0.0);
+      } else v = 0.0;
+    } else v = (i == j) ? 1.0 : 0.0;
+    Sp[i + (int64_t)n_pad * j] = v;
+  }
 }
 
 int launch_k_build(hipStream_t st, const double *x, int64_t x_stride, int n, int n_pad, int batch,
                    double ls, double sf, double jitter, double *S, bool full) {
-  dim3 block(256), grid((n_pad + 255) / 256, n_pad, batch);
+  static_assert(TILE % KB_COLS == 0, "columns per thread");
+  dim3 block(256), grid((n_pad + 255) / 256, n_pad / KB_COLS, batch);
   hipLaunchKernelGGL(k_build_kernel, grid, block, 0, st, x, x_stride, n, n_pad, 1.0 / (ls * ls),
                      sf * sf, jitter, S, full ? 1 : 0);
   GP_HIP(hipGetLastError());
