@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (vendor data sheet; 256 CUs x 128 flop/clk x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
-SETUP_SWEEPS = 5
+SETUP_SWEEPS = 9
 
 
 def dense_flops(n, m, G):
@@ -32,7 +32,7 @@ def dense_flops(n, m, G):
     return dict(potrf=n ** 3 / 3.0, nu=float(n) * n * m, fstar=2.0 * n * n * m + 2.0 * G * n * m)
 
 
-def substeps(n, m, C, G, ms, evals, r0=0):
+def substeps(n, m, C, G, ms, evals, r0=0, lookahead=False):
     """Achieved rate of every sub-step of the sweep from its ALGORITHMIC work (the counts of the
     reference's formulation: Cholesky n^3/3, L*Z n^2 m, f* by two triangular solves per item
     2 n^2 m + 2 G n m, a likelihood pass n m cells of 8 B f + 1 B y, an f proposal 17 B/cell)
@@ -49,7 +49,7 @@ def substeps(n, m, C, G, ms, evals, r0=0):
     out = {
         "potrf": {"ms": ms["potrf"], "algorithmic_flop": n ** 3 / 3.0 + fl_beside,
                   "tflops": rate(n ** 3 / 3.0 + fl_beside, ms["potrf"]),
-                  "rows_of_nu_computed_beside_it": r0},
+                  "rows_of_nu_computed_beside_it": r0, "lookahead": lookahead},
         "nu=L*Z": {"ms": ms["nu"], "algorithmic_flop": fl_after, "tflops": rate(fl_after, ms["nu"]),
                    "rows": [r0, n]},
         "fstar": {"ms": ms["fstar"], "algorithmic_flop": 2.0 * n * n * m + 2.0 * G * n * m,
@@ -269,11 +269,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # the sampler times its first five sweeps of the dense route to choose between computing the
-    # first rows of nu = L*Z beside the factorisation or after it (same chain bit for bit):
-    # that choice is part of the set-up, before the warm-up steps.  Its second sweep still runs
-    # the whole product as one launch after the factorisation: that launch's time is kept for
-    # the roofline report.
+    # the sampler times its first sweeps of the dense route (two per schedule, up to four
+    # schedules) to choose whether the first rows of nu = L*Z run beside the factorisation and
+    # whether the factorisation runs its trailing updates beside the next block columns' steps
+    # (same chain bit for bit): that choice is part of the set-up, before the warm-up steps.  Its
+    # second sweep runs the plain schedule, the whole product as one launch after the
+    # factorisation: those times are kept for the roofline report.
     s.sweep(1)
     pa = s.phase_times()
     s.sweep(1)
@@ -295,6 +296,7 @@ def main():
     d1 = s.diagnostics()
     up1 = s.update_times()
     r0 = min(s.nu_rows_beside_factor(), n)
+    lookahead = s.factor_lookahead()
     elapsed = max_over_ranks(elapsed)
 
     # The same sweep with the prior factor kept in generator form (GPIRT_GENERATOR_PRIOR): the
@@ -352,7 +354,7 @@ def main():
         nu_achieved = fl_launch / (nu_ms * 1e-3) / 1e12 if nu_ms > 0 else 0.0
         upd_ms, upd_n, upd_fl = up1[0] - up0[0], up1[1] - up0[1], up1[2] - up0[2]
         upd_achieved = upd_fl / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
-        upd_pmc = pmc_kernel(rec, "syrk", n, m, world)
+        upd_pmc = None if lookahead else pmc_kernel(rec, "syrk", n, m, world)
         nu_pmc = pmc_kernel(rec, "nu_rest" if r0 > 0 else "nu_whole", n, m, world)
         evals = {k: (d1[k] - d0[k]) / args.steps for k in ("ess_f_rounds", "ess_param_rounds", "ess_theta_rounds")}
         dense_ms = phases["potrf"] + phases["nu"]     # the f* step no longer runs its algorithmic count
@@ -377,8 +379,11 @@ def main():
                                       "stream-ordered" if native is not None else
                                       "gloo through host memory (rehearsal)" if rehearsal else "torch.distributed nccl")},
             "roofline": {
-                "kernel": "gemm_direct_kernel<true,1> (rank-512 trailing updates of the blocked Cholesky, lower "
-                          "tiles only): the kernel with the largest share of device time",
+                "kernel": ("gemm_direct_lone_kernel<true,1> (rank-512 trailing updates of the blocked Cholesky, lower "
+                           "tiles only, on the second stream beside the next block columns' steps: fixed grid, one "
+                           "workgroup to a CU)" if lookahead else
+                           "gemm_direct_kernel<true,1> (rank-512 trailing updates of the blocked Cholesky, lower "
+                           "tiles only): the kernel with the largest share of device time"),
                 "bound": "mfma", "achieved": upd_achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": upd_achieved / FP64_MFMA_PEAK_TFLOPS,
                 "launches_per_step": upd_n / args.steps if args.steps else 0,
@@ -400,7 +405,7 @@ def main():
                         "traffic": nu_pmc["hbm_bytes_per_launch"] if nu_pmc else None},
                 },
             },
-            "substeps": substeps(n, mloc, C, cfg.n_grid, phases, evals, r0),
+            "substeps": substeps(n, mloc, C, cfg.n_grid, phases, evals, r0, lookahead),
             "phases_ms": phases,
             "launch_marks_per_step": launches,
             "dense_tflops": (fl["potrf"] + fl["nu"]) / (dense_ms * 1e-3) / 1e12 if dense_ms > 0 else 0.0,

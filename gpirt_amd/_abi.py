@@ -95,6 +95,8 @@ class GpirtOutputs(C.Structure):
         ("ess_capped", C.c_int64),
         ("jitter_retries", C.c_int32),
         ("nu_rows_beside_factor", C.c_int32),
+        ("factor_lookahead", C.c_int32),
+        ("reserved0", C.c_int32),
         ("seconds_total", C.c_double),
     ]
 

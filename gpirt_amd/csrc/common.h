@@ -139,6 +139,8 @@ struct GemmArgs {
                      // columns from z*k_shift on, so its trimmed range ends z*k_shift earlier
   int k_base;        // k_trim 1 or 3 on a row range of the triangular matrix that starts at row
                      // k_base (A and C point at that row): the trimmed range ends k_base later
+  int lone;          // lower_only or k_trim 1, batch 1: run as a fixed grid of fewer workgroups than
+                     // CUs, one to a CU, so that another stream's small kernels find room beside it
 };
 // C = alpha * op(A) * op(B) + beta * C.
 //   AT = false: A(i,k) at A[i + lda*k];  AT = true: A(i,k) at A[k + lda*i]
@@ -173,9 +175,20 @@ inline int64_t potrf_work_elems(int n_pad, int batch) {
 // `timer` (optional) is called right before (begin = 1) and right after (begin = 0) the launch of
 // each rank-512 trailing update, with that launch's algorithmic flop count: the caller may bracket
 // the launch with events of its own.
+// `side` (optional, batch 1): a second stream for the look-ahead schedule.  The rank-512 update
+// behind super-panel s is split: its first four block columns (all that the chain of small
+// kernels of super-panel s+1 needs) stay on `st`; the rest runs on `side` as a fixed grid of
+// fewer workgroups than CUs, beside that chain.  `ev` must hold 2 * ceil(nb / 4) events.  The
+// arithmetic per tile is that of the plain schedule: same factor bit for bit.  In stream order
+// on `st` the factor is still final when the call returns.  With `side`, `fn` is called when block
+// columns [o, oe) are final on `st` and the side stream's share of the update behind them is
+// enqueued: what `fn` puts on `side` runs behind that share; `timer` brackets the side stream's
+// launches (its `stream` argument says where to record).
 struct PotrfHook {
   int (*fn)(void *ctx, int o, int oe); void *ctx;
-  int (*timer)(void *ctx, int begin, double flop);
+  int (*timer)(void *ctx, int begin, double flop, hipStream_t stream);
+  hipStream_t side;
+  hipEvent_t *ev;
 };
 // mode bits:
 //   POTRF_DEFER_INVERSES  the inverted diagonal (super-)blocks, which only callers that multiply by

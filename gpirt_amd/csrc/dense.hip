@@ -6,6 +6,7 @@
 //   nu = L z               utils/elliptical_slice.m:64
 //   S^-1 B                 the solve inside gp(...), main.m:57-58
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace gpirt {
@@ -338,7 +339,11 @@ constexpr int DKB = 8;       // k-values per block
 #ifndef GPIRT_DNBUF
 #define GPIRT_DNBUF 3
 #endif
-constexpr int DNBUF = GPIRT_DNBUF;   // blocks of fragments held in registers
+constexpr int DNBUF_DEFAULT = GPIRT_DNBUF;   // blocks of fragments held in registers
+#ifndef GPIRT_LONE_NBUF
+#define GPIRT_LONE_NBUF 3
+#endif
+constexpr int LONE_NBUF = GPIRT_LONE_NBUF;
 
 __device__ __forceinline__ double ld_f64(const double *base, uint32_t off) {
   return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + off);
@@ -347,11 +352,18 @@ __device__ __forceinline__ double2 ld_f64x2(const double *base, uint32_t off) {
   return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + off);
 }
 
-template <bool BT, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs g, int nbm, int nbn) {
+// Fragment layout.  An operand whose tile index is contiguous in memory (A always; B when BT) is
+// taken in 16-byte loads of TWO neighbouring rows per lane: lane lr of a 32-row group holds rows
+// 2 lr and 2 lr + 1, which become the lane's entries of two MFMA tiles (the even and the odd rows of
+// the group).  Half the load instructions of one row per lane per tile -- the vector memory pipe
+// handles an 8-byte access at little more than half the byte rate of a 16-byte one, and with one
+// row per lane it, not the matrix unit, set the pace -- and the accumulators of such a tile pair
+// leave as 16-byte stores.  The sum over k of every element of C is formed in the same order.
+template <bool BT, int MODE, int DNBUF>
+__device__ __forceinline__ void gemm_direct_tile(const GemmArgs &g, int nbm, int nbn, int t) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int t = blockIdx.x, bi, bj;
+  int bi, bj;
   if (MODE == 1) {
     bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
     while ((int64_t)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
@@ -378,6 +390,14 @@ __global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs g, int nbm
   if (MODE == 2 || MODE == 4 || MODE == 5) kend = min(g.K, (bi + 1) * TILE + g.k_base - z * g.k_shift);   // may be <= 0: a zero tile
   const double alpha = g.alpha, beta = g.beta;
   double *C = g.C + g.strideC * z;   // may alias A or B (in-place panel and solve steps)
+  // accumulator acc[tj][ti][r] of lane (lr, lk) is C(row(ti), col(tj, r)) with
+  //   row(ti)    = i0 + 32 (ti / 2) + 2 lr + (ti & 1)
+  //   col(tj, r) = j0 + 16 tj + lk + 4 r                              (B with K contiguous)
+  //              = j0 + 32 (tj / 2) + 2 (lk + 4 r) + (tj & 1)         (BT: B's columns in pairs too)
+  double *Cw = C + i0 + 2 * lr;
+  auto col = [&](int tj, int r) -> int {
+    return BT ? j0 + 32 * (tj >> 1) + 2 * (lk + 4 * r) + (tj & 1) : j0 + 16 * tj + lk + 4 * r;
+  };
 
   v4d acc[4][4];
   if (beta != 0.0) {
@@ -385,10 +405,13 @@ __global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs g, int nbm
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-      for (int ti = 0; ti < 4; ++ti)
+      for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc[tj][ti][r] = sc * C[(i0 + ti * 16 + lr) + ldc * (int64_t)(j0 + tj * 16 + lk + 4 * r)];
+        for (int r = 0; r < 4; ++r) {
+          const double2 v = *reinterpret_cast<const double2 *>(Cw + 32 * gi + ldc * (int64_t)col(tj, r));
+          acc[tj][2 * gi][r] = sc * v.x;
+          acc[tj][2 * gi + 1][r] = sc * v.y;
+        }
   } else {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -402,10 +425,10 @@ __global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs g, int nbm
     const double *Bw = g.B + g.strideB * z + (BT ? (int64_t)j0 : ldb * (int64_t)j0);
     uint32_t oa[2], ob[BT ? 2 : 4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) oa[s] = (uint32_t)((lr + lda * (2 * lk + s)) * 8);
+    for (int s = 0; s < 2; ++s) oa[s] = (uint32_t)((2 * lr + lda * (2 * lk + s)) * 8);
     if (BT) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) ob[s] = (uint32_t)((lr + ldb * (2 * lk + s)) * 8);
+      for (int s = 0; s < 2; ++s) ob[s] = (uint32_t)((2 * lr + ldb * (2 * lk + s)) * 8);
     } else {
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj) ob[tj] = (uint32_t)((2 * lk + ldb * (16 * tj + lr)) * 8);
@@ -420,12 +443,20 @@ __global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs g, int nbm
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) fa[buf][s][ti] = ld_f64(Ab + 16 * ti, oa[s]);
+        for (int gi = 0; gi < 2; ++gi) {
+          const double2 v = ld_f64x2(Ab + 32 * gi, oa[s]);
+          fa[buf][s][2 * gi] = v.x;
+          fa[buf][s][2 * gi + 1] = v.y;
+        }
       if (BT) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-          for (int tj = 0; tj < 4; ++tj) fb[buf][s][tj] = ld_f64(Bb + 16 * tj, ob[s]);
+          for (int gj = 0; gj < 2; ++gj) {
+            const double2 v = ld_f64x2(Bb + 32 * gj, ob[s]);
+            fb[buf][s][2 * gj] = v.x;
+            fb[buf][s][2 * gj + 1] = v.y;
+          }
       } else {
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
@@ -466,10 +497,31 @@ __global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs g, int nbm
 #pragma unroll
   for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
+    for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        C[(i0 + ti * 16 + lr) + ldc * (int64_t)(j0 + tj * 16 + lk + 4 * r)] = alpha * acc[tj][ti][r];
+        *reinterpret_cast<double2 *>(Cw + 32 * gi + ldc * (int64_t)col(tj, r)) =
+            make_double2(alpha * acc[tj][2 * gi][r], alpha * acc[tj][2 * gi + 1][r]);
+}
+
+template <bool BT, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs g, int nbm, int nbn) {
+  gemm_direct_tile<BT, MODE, DNBUF_DEFAULT>(g, nbm, nbn, blockIdx.x);
+}
+
+// The same tiles for launches of FEWER workgroups than the chip has CUs that are to leave room for
+// another stream's kernels (the look-ahead schedule of the factorisation, the rows of nu = L*Z beside
+// it): a fixed grid walks the tile list (tile t, t + gridDim.x, ...), and with four blocks of
+// fragments in flight a workgroup holds more than half of a SIMD's registers, so that no two of them
+// share a CU -- the dispatcher otherwise packs such a grid two to a CU and leaves half the chip idle.
+// Alone on its CU a workgroup needs the deeper prefetch anyway.
+template <bool BT, int MODE>
+__global__ __launch_bounds__(256) void gemm_direct_lone_kernel(GemmArgs g, int nbm, int nbn, int ntiles) {
+#pragma nounroll
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    gemm_direct_tile<BT, MODE, LONE_NBUF>(g, nbm, nbn, t);
+    __syncthreads();   // the next tile's loads stay behind this tile's stores
+  }
 }
 
 // The register-fed loop on 64x64 tiles for the products with few tiles and a short K (the in-panel
@@ -616,6 +668,20 @@ static int small_lower_tiles() {
   return v;
 }
 
+// the register-fed kernels take rows in 16-byte pairs: every operand 16-byte aligned, even strides
+static bool pairs_aligned(const GemmArgs &a) {
+  const uintptr_t p = (uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C;
+  const int64_t l = a.lda | a.ldb | a.ldc | a.strideA | a.strideB | a.strideC;
+  return p % 16 == 0 && l % 2 == 0;
+}
+
+// workgroups of a fixed-grid launch: one per CU on 7 of every 8 CUs, so that every shader engine
+// keeps a CU free (the dispatcher binds a waiting workgroup to a shader engine before it looks for room)
+static int persist_workgroups() {
+  static const int v = getenv("GPIRT_PERSIST_WGS") ? std::max(1, atoi(getenv("GPIRT_PERSIST_WGS"))) : 224;
+  return v;
+}
+
 int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
   if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return GPIRT_OK;
   if (a.M % TILE || a.N % TILE || a.K % BK || a.K <= 0) {
@@ -625,6 +691,11 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
   int nbm = a.M / TILE, nbn = a.N / TILE;
   int mode = a.lower_only ? 1 : (a.k_trim == 1 ? 2 : (a.k_trim == 2 ? 3 : (a.k_trim == 3 ? 4 : (a.k_trim == 4 ? 5 : 0))));
   int64_t tiles = a.lower_only ? (int64_t)nbm * (nbm + 1) / 2 : (int64_t)nbm * nbn;
+  // lone: a fixed grid of at most persist_workgroups() workgroups, one to a CU (the small 64 x 64
+  // variant below still takes the launches with few tiles)
+  const bool lone = a.lone && a.batch == 1 && !AT && !gemm_lds_only() && pairs_aligned(a) && a.k_base % BK == 0 && a.k_shift % BK == 0 &&
+                    a.lda * 4 * 8 < (int64_t)1 << 31 && a.ldb * 80 * 8 < (int64_t)1 << 31 &&
+                    ((mode == 1 && BT && tiles > small_lower_tiles()) || (mode == 2 && !BT));
   if (mode == 4) {   // whole 8x4 super-tiles, a multiple of 8 of them (one share per XCD)
     int64_t nsup = (int64_t)((nbm + 7) / 8) * ((nbn + 3) / 4);
     tiles = (nsup + 7) / 8 * 8 * 32;
@@ -649,9 +720,16 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
     GP_HIP(hipGetLastError());
     return GPIRT_OK;
   }
+  if (lone) {
+    const dim3 lgrid((unsigned)std::min<int64_t>(tiles, persist_workgroups()));
+    if (mode == 1) hipLaunchKernelGGL((gemm_direct_lone_kernel<true, 1>), lgrid, dim3(256), 0, st, a, nbm, nbn, (int)tiles);
+    else hipLaunchKernelGGL((gemm_direct_lone_kernel<false, 2>), lgrid, dim3(256), 0, st, a, nbm, nbn, (int)tiles);
+    GP_HIP(hipGetLastError());
+    return GPIRT_OK;
+  }
   dim3 grid((unsigned)tiles, (unsigned)a.batch);
   static_assert(BK % DKB == 0, "K granularity");
-  if (!AT && !gemm_lds_only() && a.k_base % BK == 0 && a.k_shift % BK == 0 && a.lda * 4 * 8 < (int64_t)1 << 31 && a.ldb * 80 * 8 < (int64_t)1 << 31) {
+  if (!AT && !gemm_lds_only() && a.k_base % BK == 0 && a.k_shift % BK == 0 && a.lda * 4 * 8 < (int64_t)1 << 31 && a.ldb * 80 * 8 < (int64_t)1 << 31 && pairs_aligned(a)) {
     if (!BT && (mode == 0 || mode == 2 || mode == 4 || mode == 5)) return launch_direct_mode<false>(st, a, mode, grid, nbm, nbn);
     if (BT && (mode == 0 || mode == 1)) return launch_direct_mode<true>(st, a, mode, grid, nbm, nbn);
   }
@@ -946,27 +1024,60 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
     u.alpha = -1.0; u.beta = 1.0;
     return launch_gemm(st, false, true, u);
   };
+  // the rank-(oe-o)*128 update of the lower tiles from block (r0, r0) on by block columns [o, oe)
+  auto trailing = [&](int o, int oe, int r0, int fixed_grid) -> GemmArgs {
+    GemmArgs u{};
+    u.A = S + (int64_t)r0 * TILE + (int64_t)n_pad * o * TILE; u.lda = n_pad; u.strideA = sS;
+    u.B = u.A; u.ldb = n_pad; u.strideB = sS;
+    u.C = S + (int64_t)r0 * TILE * (n_pad + 1); u.ldc = n_pad; u.strideC = sS;
+    u.M = (nb - r0) * TILE; u.N = u.M; u.K = (oe - o) * TILE; u.batch = batch;
+    u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1; u.lone = fixed_grid;
+    return u;
+  };
+  const bool ahead = hook && hook->side && hook->ev && batch == 1;
   for (int o = 0; o < nb; o += 4) {
-    const int oe = min(o + 4, nb);
+    const int oe = min(o + 4, nb), sp = o / 4;
     for (int k = o; k < oe; ++k) {
       GP_TRY(launch_potrf_diag(st, S, n_pad, k, batch, inv, nb, d_info, !subst));
       if (k + 1 < nb) GP_TRY(panel_solve(k));
       GP_TRY(update_rect(k, k + 1, oe));
     }
-    if (oe < nb) {
-      GemmArgs u{};
-      u.A = S + (int64_t)oe * TILE + (int64_t)n_pad * o * TILE; u.lda = n_pad; u.strideA = sS;
-      u.B = u.A; u.ldb = n_pad; u.strideB = sS;
-      u.C = S + (int64_t)oe * TILE * (n_pad + 1); u.ldc = n_pad; u.strideC = sS;
-      u.M = (nb - oe) * TILE; u.N = u.M; u.K = (oe - o) * TILE; u.batch = batch;
-      u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
+    if (oe < nb && !ahead) {
+      GemmArgs u = trailing(o, oe, oe, 0);
       const double r = (double)(nb - oe);
       const double flop = r * (r + 1.0) * 0.5 * 2.0 * TILE * TILE * (double)u.K * batch;   // lower tiles only
       // timed: the launches of the 128 x 128-tile kernel (the last, small updates run on 64 x 64 tiles)
       const bool timed = hook && hook->timer && r * (r + 1.0) * 0.5 * batch > small_lower_tiles();
-      if (timed) GP_TRY(hook->timer(hook->ctx, 1, flop));
+      if (timed) GP_TRY(hook->timer(hook->ctx, 1, flop, st));
       GP_TRY(launch_gemm(st, false, true, u));
-      if (timed) GP_TRY(hook->timer(hook->ctx, 0, flop));
+      if (timed) GP_TRY(hook->timer(hook->ctx, 0, flop, st));
+    }
+    if (oe < nb && ahead) {
+      // look-ahead: block columns [oe, oe + 4) are all that the next chain needs
+      const int pe = min(oe + 4, nb);
+      if (pe < nb) {
+        GP_HIP(hipEventRecord(hook->ev[2 * sp], st));              // panel sp is final
+        GP_HIP(hipStreamWaitEvent(hook->side, hook->ev[2 * sp], 0));
+        GemmArgs u = trailing(o, oe, pe, 1);
+        const double r = (double)(nb - pe);
+        const double flop = r * (r + 1.0) * 0.5 * 2.0 * TILE * TILE * (double)u.K;
+        const bool timed = hook->timer && r * (r + 1.0) * 0.5 > small_lower_tiles();
+        if (timed) GP_TRY(hook->timer(hook->ctx, 1, flop, hook->side));
+        GP_TRY(launch_gemm(hook->side, false, true, u));
+        if (timed) GP_TRY(hook->timer(hook->ctx, 0, flop, hook->side));
+        GP_HIP(hipEventRecord(hook->ev[2 * sp + 1], hook->side));  // the side stream's share of update sp is done
+      }
+      if (hook->fn) GP_TRY(hook->fn(hook->ctx, o, oe));
+      // the strip the next chain needs: it was last written by the side stream's share of update sp - 1
+      if (sp > 0 && min(o + 4, nb) < nb) GP_HIP(hipStreamWaitEvent(st, hook->ev[2 * (sp - 1) + 1], 0));
+      GemmArgs p{};
+      p.A = S + (int64_t)oe * TILE + (int64_t)n_pad * o * TILE; p.lda = n_pad; p.strideA = sS;
+      p.B = p.A; p.ldb = n_pad; p.strideB = sS;
+      p.C = S + (int64_t)oe * TILE * (n_pad + 1); p.ldc = n_pad; p.strideC = sS;
+      p.M = (nb - oe) * TILE; p.N = (pe - oe) * TILE; p.K = (oe - o) * TILE; p.batch = 1;
+      p.alpha = -1.0; p.beta = 1.0;
+      GP_TRY(launch_gemm(st, false, true, p));
+      continue;
     }
     if (hook && hook->fn) GP_TRY(hook->fn(hook->ctx, o, oe));
   }

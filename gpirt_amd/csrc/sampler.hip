@@ -175,21 +175,30 @@ struct gpirt_sampler {
   // nu = L Z beside the factorisation: the rows of the first nu_overlap super-panels (SUP rows
   // each) are computed on a second stream, in chunks of nu_chunk tile rows, once those rows of L
   // are final and the trailing update that followed them has drained -- beside the next
-  // super-panels' chain of small kernels, which leaves most CUs idle.  A chunk is sized to put
-  // one workgroup on most CUs and leave some CUs empty: the diagonal-block kernel needs a whole
-  // CU's LDS.  The result is the same bit for bit (same per-tile arithmetic), so the sampler
-  // times the factor + nu span with and without it in its first sweeps and keeps the faster.
+  // super-panels' chain of small kernels, which leaves most CUs idle.  A chunk puts one workgroup
+  // on most CUs and leaves some CUs empty: the diagonal-block kernel needs a whole CU.
+  // Look-ahead (launch_potrf with a side stream): the bulk of each trailing update runs on the
+  // second stream beside the next super-panel's chain.
+  // Either leaves the chain the same bit for bit (same per-tile arithmetic), and which
+  // combination is fastest depends on the share of the items this rank holds, so the sampler
+  // times the factor + nu span of every combination it may use in its first sweeps (two sweeps
+  // each, the second one timed) and keeps the fastest.
   hipStream_t st2;
+  int lookahead;       // look-ahead may be used (1), is forced (2)
+  int nu_lone;         // the chunks of nu beside the factorisation run one workgroup to a CU
+  std::vector<hipEvent_t> ev_ahead;
   std::vector<hipEvent_t> ev_panel;
-  hipEvent_t ev_join, ev_z, ev_pref, ev_span[2][2];
-  int pref_on_st2;     // this sweep's input-only factors of the low-rank f* step went to the second stream   // [sweep parity][begin, end] of the factor + nu span
+  hipEvent_t ev_join, ev_z, ev_pref, ev_span[2][2];   // [sweep parity][begin, end] of the factor + nu span
+  int pref_on_st2;     // this sweep's input-only factors of the low-rank f* step went to the second stream
   int nu_overlap, nu_chunk, nu_rows_done, z_filled;
-  int ov_now;          // this sweep computes rows beside the factorisation
-  int ov_choice;       // -1: still measuring; 0 / 1: decided (or forced)
+  int ov_now;          // this sweep computes rows of nu beside the factorisation
+  int la_now;          // this sweep factors with look-ahead
+  int sched_cand[4], sched_ncand;   // schedules to choose from: bit 0 rows of nu beside, bit 1 look-ahead
+  int sched_choice;    // -1: still measuring; else the schedule in use
   int dense_sweeps;    // sweeps that took the dense route so far
   int span_open;       // parity + 1 of the span this sweep has begun (0: none)
-  int span_kind[2];    // what the span of that parity measured: -1 nothing, 0 without, 1 with
-  float ov_ms[2];      // measured span without / with
+  int span_kind[2];    // the candidate whose span of that parity was measured (-1: none)
+  float sched_ms[4];   // measured span per candidate
 };
 
 static void sampler_free(gpirt_sampler *s) {
@@ -208,6 +217,7 @@ static void sampler_free(gpirt_sampler *s) {
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->upd_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_panel) (void)hipEventDestroy(e);
+  for (hipEvent_t e : s->ev_ahead) (void)hipEventDestroy(e);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->ev_z) (void)hipEventDestroy(s->ev_z);
   if (s->ev_pref) (void)hipEventDestroy(s->ev_pref);
@@ -585,7 +595,12 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     if (want > 1) A_(s->d_nuparts, (size_t)want * Np_pad * ML);
   }
   s->nu_overlap = 0;
-  s->ov_choice = 0;
+  // look-ahead in the factorisation: one IRF group, from 4096 inputs on; GPIRT_LOOKAHEAD=0 / 1
+  // takes it out of / forces it into the schedule
+  const char *la_env = getenv("GPIRT_LOOKAHEAD");
+  s->lookahead = P == 1 && Np_pad >= 8 * SUP && !(la_env && atoi(la_env) == 0) ? (la_env ? 2 : 1) : 0;
+  s->nu_lone = !(getenv("GPIRT_NU_LONE") && atoi(getenv("GPIRT_NU_LONE")) == 0);
+  int ov_forced = 0;
   if (s->nu_splits == 1 && Np_pad >= 8 * SUP && !(cfg->flags & GPIRT_NO_NU_OVERLAP)) {
     // GPIRT_NU_OVERLAP=k forces k super-panels (0: none) and GPIRT_NU_CHUNK=t the chunk size;
     // by default the rows left for the launch after the factorisation make at most 512 tiles
@@ -594,25 +609,37 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     const char *e = getenv("GPIRT_NU_OVERLAP"), *c = getenv("GPIRT_NU_CHUNK");
     int k = (s->nb - 512 / ncol + 3) / 4;
     k = max((nsup + 1) / 2, min(k, nsup - 2));
-    s->nu_overlap = e ? min(atoi(e), nsup) : k;
-    s->ov_choice = e ? 1 : -1;
+    s->nu_overlap = max(0, e ? min(atoi(e), nsup) : k);
+    ov_forced = e != nullptr;
     s->nu_chunk = c ? max(1, atoi(c)) : max(1, min(16, 224 / ncol));
-    if (s->nu_overlap > 0) {
-      bool ok = hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking) == hipSuccess &&
-                hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&s->ev_z, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&s->ev_pref, hipEventDisableTiming) == hipSuccess;
-      for (int a = 0; a < 2 && ok; ++a)
-        for (int b = 0; b < 2 && ok; ++b) ok = hipEventCreate(&s->ev_span[a][b]) == hipSuccess;
-      for (int i = 0; i < s->nu_overlap && ok; ++i) {
-        hipEvent_t ev;
-        ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
-        if (ok) s->ev_panel.push_back(ev);
-      }
-      if (!ok) { set_error("second stream: creation failed"); return fail(GPIRT_ERR_HIP); }
-    } else {
-      s->ov_choice = 0;
+  }
+  // the schedules this sampler may use, plainest first
+  s->sched_ncand = 0;
+  for (int c = 0; c < 4; ++c) {
+    const bool ov = c & 1, la = c & 2;
+    if (ov ? s->nu_overlap == 0 : (ov_forced && s->nu_overlap > 0)) continue;
+    if (la ? s->lookahead == 0 : s->lookahead == 2) continue;
+    s->sched_cand[s->sched_ncand++] = c;
+  }
+  s->sched_choice = s->sched_ncand == 1 ? s->sched_cand[0] : -1;
+  if (s->nu_overlap > 0 || s->lookahead) {
+    bool ok = hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_z, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_pref, hipEventDisableTiming) == hipSuccess;
+    for (int a = 0; a < 2 && ok; ++a)
+      for (int b = 0; b < 2 && ok; ++b) ok = hipEventCreate(&s->ev_span[a][b]) == hipSuccess;
+    for (int i = 0; i < s->nu_overlap && ok; ++i) {
+      hipEvent_t ev;
+      ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+      if (ok) s->ev_panel.push_back(ev);
     }
+    for (int i = 0; s->lookahead && i < 2 * inv_nsup(Np_pad) && ok; ++i) {
+      hipEvent_t ev;
+      ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+      if (ok) s->ev_ahead.push_back(ev);
+    }
+    if (!ok) { set_error("second stream: creation failed"); return fail(GPIRT_ERR_HIP); }
   }
   s->span_kind[0] = s->span_kind[1] = -1;
   if (cfg->theta_mode == GPIRT_THETA_GRID) {
@@ -747,14 +774,14 @@ static int collect_times(gpirt_sampler *s) {
 }
 
 // brackets one trailing update of the factorisation with a pair of events (see PotrfHook)
-static int update_timer(void *ctx, int begin, double flop) {
+static int update_timer(void *ctx, int begin, double flop, hipStream_t stream) {
   gpirt_sampler *s = (gpirt_sampler *)ctx;
   if (s->upd_used == s->upd_ev.size()) {
     hipEvent_t e;
     GP_HIP(hipEventCreate(&e));
     s->upd_ev.push_back(e);
   }
-  GP_HIP(hipEventRecord(s->upd_ev[s->upd_used++], s->st));
+  GP_HIP(hipEventRecord(s->upd_ev[s->upd_used++], stream));
   if (!begin) s->upd_flop_pending += flop;
   return GPIRT_OK;
 }
@@ -854,7 +881,9 @@ static int nu_panel_hook(void *ctx, int o, int oe) {
       GP_HIP(hipStreamWaitEvent(s->st2, s->ev_panel[sp], 0));
       recorded = true;
     }
-    GP_TRY(launch_gemm(s->st2, false, false, nu_args(s, t * TILE, t1 * TILE)));
+    GemmArgs c = nu_args(s, t * TILE, t1 * TILE);
+    c.lone = s->nu_lone;
+    GP_TRY(launch_gemm(s->st2, false, false, c));
     s->nu_rows_done = t1 * TILE;
     t = t1;
   }
@@ -862,17 +891,23 @@ static int nu_panel_hook(void *ctx, int o, int oe) {
 }
 
 // The span measured in the sweep before this one is complete once this sweep's factorisation
-// has been waited for: sweeps 1 and 3 of the dense route are the measurements without and with
-// the rows beside the factorisation (0 and 2 warm each setting up), then the faster one stays.
-static int overlap_tune(gpirt_sampler *s) {
-  if (s->ov_choice >= 0) return GPIRT_OK;
+// has been waited for.  Candidate c runs in the dense route's sweeps 2c (warming up) and 2c + 1
+// (timed); once every candidate has its time the fastest stays, a plainer one unless the other is
+// 2 % faster.
+static int schedule_tune(gpirt_sampler *s) {
+  if (s->sched_choice >= 0) return GPIRT_OK;
   const int prev = (s->dense_sweeps + 1) & 1, kind = s->span_kind[prev];
   if (kind >= 0) {
     float ms = 0;
     GP_HIP(hipEventElapsedTime(&ms, s->ev_span[prev][0], s->ev_span[prev][1]));
-    s->ov_ms[kind] = ms;
+    s->sched_ms[kind] = ms;
     s->span_kind[prev] = -1;
-    if (kind == 1) s->ov_choice = s->ov_ms[1] < 0.98f * s->ov_ms[0] ? 1 : 0;
+    if (kind == s->sched_ncand - 1) {
+      int best = 0;
+      for (int c = 1; c < s->sched_ncand; ++c)
+        if (s->sched_ms[c] < 0.98f * s->sched_ms[best]) best = c;
+      s->sched_choice = s->sched_cand[best];
+    }
   }
   return GPIRT_OK;
 }
@@ -897,16 +932,26 @@ static int phase_factor(gpirt_sampler *s) {
     GP_TRY(phase_factor_generator(s, &done));
     if (done) { s->gen_now = 1; return GPIRT_OK; }
   }
-  s->ov_now = s->nu_overlap > 0 && (s->ov_choice >= 0 ? s->ov_choice : s->dense_sweeps >= 2);
   const int par = s->dense_sweeps & 1;
-  if (s->ov_choice < 0) {
+  int sched = s->sched_choice;
+  if (sched < 0) {
+    const int ci = min(s->dense_sweeps / 2, s->sched_ncand - 1);
+    sched = s->sched_cand[ci];
     GP_HIP(hipEventRecord(s->ev_span[par][0], s->st));
-    s->span_kind[par] = s->dense_sweeps == 1 ? 0 : (s->dense_sweeps == 3 ? 1 : -1);
+    s->span_kind[par] = (s->dense_sweeps & 1) && s->dense_sweeps / 2 < s->sched_ncand ? ci : -1;
     s->span_open = par + 1;
   }
-  PotrfHook hook{nullptr, s, update_timer};
-  for (;;) {
+  s->ov_now = sched & 1;
+  s->la_now = (sched & 2) != 0;
+  PotrfHook hook{nullptr, s, update_timer, nullptr, nullptr};
+  if (s->la_now) { hook.side = s->st2; hook.ev = s->ev_ahead.data(); }
+  for (int attempt = 0;; ++attempt) {
     s->nu_rows_done = 0;
+    if (attempt && s->st2) {
+      // a failed attempt's launches on the second stream still read and write the matrix
+      GP_HIP(hipEventRecord(s->ev_join, s->st2));
+      GP_HIP(hipStreamWaitEvent(s->st, s->ev_join, 0));
+    }
     GP_TRY(mark(s, PH_KBUILD));
     GP_TRY(launch_k_build(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->cfg.irf_ls,
                           s->cfg.irf_sf, s->jitter_now, s->d_S, false));
@@ -939,7 +984,7 @@ static int phase_factor(gpirt_sampler *s) {
     s->theta_inside = !s->h_look[1];
     const int info = s->h_look[0];
     if (!info) {
-      GP_TRY(overlap_tune(s));
+      GP_TRY(schedule_tune(s));
       s->dense_sweeps++;
       return GPIRT_OK;
     }
@@ -1422,6 +1467,7 @@ int gpirt_sampler_diagnostics(gpirt_sampler *s, gpirt_outputs *o) {
   o->ess_capped = (int64_t)(c[1] + c[3] + c[5]);
   o->jitter_retries = s->jitter_retries;
   o->nu_rows_beside_factor = s->gen_now ? 0 : s->nu_rows_done;
+  o->factor_lookahead = s->gen_now ? 0 : s->la_now;
   return GPIRT_OK;
 }
 

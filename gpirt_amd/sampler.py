@@ -115,6 +115,13 @@ class Sampler:
         check(lib().gpirt_sampler_diagnostics(self._h, C.byref(o)))
         return int(o.nu_rows_beside_factor)
 
+    def factor_lookahead(self):
+        """True if the last sweep's factorisation ran its trailing updates on the second stream,
+        beside the next block columns' steps."""
+        o = _abi.GpirtOutputs()
+        check(lib().gpirt_sampler_diagnostics(self._h, C.byref(o)))
+        return bool(o.factor_lookahead)
+
     def accumulate(self, quadratic=False, skip_theta=False):
         """Add the current state to the device-side running sums of the posterior summaries
         (`skip_theta`: leave theta out of this draw's sums)."""

@@ -156,6 +156,9 @@ typedef struct gpirt_outputs {
   int32_t jitter_retries;     /* Cholesky retries with 10x jitter                       */
   int32_t nu_rows_beside_factor; /* rows of nu = L Z computed beside the factorisation in the
                                     last sweep (0: one launch after it)                    */
+  int32_t factor_lookahead;   /* 1: the last sweep's factorisation ran its trailing updates
+                                 on the second stream beside the next block columns' steps */
+  int32_t reserved0;
   double seconds_total;       /* wall time inside the sweep loop                        */
 } gpirt_outputs;
 

@@ -135,29 +135,35 @@ def test_sweep_invariants(flags):
 
 def test_rows_of_nu_beside_the_factorisation_leave_the_chain_unchanged(monkeypatch):
     """nu = L Z (elliptical_slice.m:64, sample_fs.m:2): the rows whose part of L is final may be
-    computed on a second stream while the factorisation goes on.  Same tiles, same arithmetic
-    per tile: six sweeps give the same chain bit for bit with the rows of 12 super-panels
-    computed that way (forced), with the sampler's own choice (it times both ways in its first
-    sweeps), and with one launch after the factorisation (GPIRT_NO_NU_OVERLAP)."""
+    computed on a second stream while the factorisation goes on, and the factorisation may run
+    the bulk of each trailing update on that stream beside the next block columns' steps
+    (look-ahead).  Same tiles, same arithmetic per tile: six sweeps give the same chain bit for
+    bit with the rows of 12 super-panels computed that way (forced), with look-ahead forced (with
+    and without those rows), with the sampler's own choice (it times the schedules in its first
+    sweeps), and with the plain schedule (GPIRT_NO_NU_OVERLAP, GPIRT_LOOKAHEAD=0)."""
     from gpirt_amd.sampler import Sampler
     from gpirt_amd.synth import generate
     d = generate(N, M, C, seed=1)
 
-    def chain(flags, forced):
-        if forced is None:
-            monkeypatch.delenv("GPIRT_NU_OVERLAP", raising=False)
-        else:
-            monkeypatch.setenv("GPIRT_NU_OVERLAP", str(forced))
+    def chain(flags, forced, ahead):
+        for name, v in (("GPIRT_NU_OVERLAP", forced), ("GPIRT_LOOKAHEAD", ahead)):
+            if v is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, str(v))
         cfg = _abi.default_config(n=N, m=M, H=1, C=C, seed=3, flags=flags)
         with Sampler(cfg, d["y"], theta_init=d["theta"]) as s:
             s.sweep(6)
-            return s.state(fstar=False), s.nu_rows_beside_factor(), s.diagnostics()
+            return s.state(fstar=False), s.nu_rows_beside_factor(), s.factor_lookahead(), s.diagnostics()
 
-    base, rows0, dg0 = chain(_abi.NO_NU_OVERLAP, None)
-    forced, rows1, dg1 = chain(0, 12)
-    own, rows2, dg2 = chain(0, None)
-    assert rows0 == 0 and rows1 == 12 * 512 and rows2 in (0, 16 * 512)
-    assert dg0 == dg1 == dg2
-    for k in ("theta", "f", "beta"):
-        assert np.array_equal(base[k], forced[k]), k
-        assert np.array_equal(base[k], own[k]), k
+    base, rows0, la0, dg0 = chain(_abi.NO_NU_OVERLAP, None, 0)
+    assert rows0 == 0 and not la0
+    for flags, forced, ahead, rows_ok, la_ok in ((0, 12, 0, (12 * 512,), (False,)),
+                                                 (0, 12, 1, (12 * 512,), (True,)),
+                                                 (_abi.NO_NU_OVERLAP, None, 1, (0,), (True,)),
+                                                 (0, None, None, (0, 16 * 512), (False, True))):
+        st, rows, la, dg = chain(flags, forced, ahead)
+        assert rows in rows_ok and la in la_ok, (flags, forced, ahead, rows, la)
+        assert dg == dg0
+        for k in ("theta", "f", "beta"):
+            assert np.array_equal(base[k], st[k]), (k, flags, forced, ahead)
