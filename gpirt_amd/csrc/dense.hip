@@ -511,10 +511,16 @@ __global__ __launch_bounds__(256, 2) void gemm_direct_kernel(GemmArgs g, int nbm
 
 // The same tiles for launches of FEWER workgroups than the chip has CUs that are to leave room for
 // another stream's kernels (the look-ahead schedule of the factorisation, the rows of nu = L*Z beside
-// it): a fixed grid walks the tile list (tile t, t + gridDim.x, ...), and with four blocks of
-// fragments in flight a workgroup holds more than half of a SIMD's registers, so that no two of them
-// share a CU -- the dispatcher otherwise packs such a grid two to a CU and leaves half the chip idle.
-// Alone on its CU a workgroup needs the deeper prefetch anyway.
+// it): a fixed grid walks the tile list (tile t, t + gridDim.x, ...).  Compiled without the
+// two-waves-per-SIMD bound a workgroup holds more than half of a SIMD's registers (accumulators in
+// AGPRs: ~360 of 512), so no two of them share a CU -- a grid of the standard kernel that is smaller
+// than the chip is packed two workgroups to a CU and leaves half the CUs idle (224 workgroups ran at
+// 29 TFLOP/s that way, 42-44 one to a CU) -- while the 64 x 64-tile kernel of the factorisation's
+// in-panel updates (132 registers) still fits beside one.  Measured: 240 or 248 workgroups run the
+// product faster (48 TFLOP/s) and the factorisation slower (its one-workgroup diagonal kernel waits
+// for a free CU: the dispatcher binds it to a shader engine before it looks for room); a fixed grid
+// of 448 workgroups of the standard kernel (two to a CU on 224 CUs) 47 TFLOP/s and the steps beside
+// it slower still; four or five blocks of fragments in flight instead of three change nothing.
 template <bool BT, int MODE>
 __global__ __launch_bounds__(256) void gemm_direct_lone_kernel(GemmArgs g, int nbm, int nbn, int ntiles) {
 #pragma nounroll
@@ -978,13 +984,6 @@ static int build_super_inverses(hipStream_t st, const double *L, int n_pad, doub
   return GPIRT_OK;
 }
 
-// Right-looking blocked Cholesky with two-level blocking: a super-panel of 4 block columns is
-// factored by 128-wide steps (diagonal kernel, panel solve with the inverted diagonal block,
-// update of the rest of the super-panel); the trailing matrix then gets ONE rank-512 update
-// (lower tiles only), which cuts the read-modify-write traffic on it four-fold.  Running the
-// next diagonal step beside a trailing update on a second stream was measured and is not
-// faster: the one-workgroup diagonal kernel needs a whole CU's LDS and only starts when the
-// update, which fills every CU, drains.
 int launch_super_inverses(hipStream_t st, const double *L, int n_pad, int batch, double *inv, double *work,
                           bool complete_blocks) {
   // after a factorisation with POTRF_SUBSTITUTION the image holds the inverted 32 x 32 diagonal
@@ -997,6 +996,17 @@ int launch_super_inverses(hipStream_t st, const double *L, int n_pad, int batch,
   return GPIRT_OK;
 }
 
+// Right-looking blocked Cholesky with two-level blocking: a super-panel of 4 block columns is
+// factored by 128-wide steps (diagonal kernel, panel solve, update of the rest of the
+// super-panel); the trailing matrix then gets ONE rank-512 update (lower tiles only), which cuts
+// the read-modify-write traffic on it four-fold.  With a side stream (PotrfHook::side) that
+// update is split: the four block columns the next super-panel's steps need stay on `st`, the
+// rest runs on the side stream beside those steps as a fixed grid that leaves CUs free -- the
+// one-workgroup diagonal kernel needs a whole CU, and beside an update that fills every CU it
+// only starts when the update drains.  (Left-looking steps inside a super-panel -- each block
+// column updated by all earlier ones in one product right before it is factored, launches a
+// third as wide -- were measured and change nothing: these launches cost what their first loads
+// and their stores cost, not what their tiles cost.)
 int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, int *d_info,
                  double *work, const PotrfHook *hook, int mode) {
   const int nb = n_pad / TILE;

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/$out
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof -- \
-  python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-variants > $R/$out/prof.log 2>&1 || { tail -5 $R/$out/prof.log; exit 1; }
+  python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-variants $BENCH_ARGS > $R/$out/prof.log 2>&1 || { tail -5 $R/$out/prof.log; exit 1; }
 f=$(find $R/$out/prof -name "*kernel_stats.csv" | head -1)
 cp "$f" $R/$out/kernel_stats.csv
 python3 - $R/$out/kernel_stats.csv <<'PY'
