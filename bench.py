@@ -282,7 +282,14 @@ def main():
     alone = s.nu_rows_beside_factor() == 0       # sweep 2 of the set-up runs nothing beside the factorisation
     nu_alone_ms = pb["nu"][0] - pa["nu"][0] if alone else None
     potrf_alone_ms = pb["potrf"][0] - pa["potrf"][0] if alone else None
-    s.sweep(SETUP_SWEEPS - 2)
+    # the sixth set-up sweep (where the sampler has that schedule to offer) is the factorisation with
+    # look-ahead and nothing else beside it
+    s.sweep(3)
+    pc = s.phase_times()
+    s.sweep(1)
+    pd = s.phase_times()
+    potrf_ahead_ms = pd["potrf"][0] - pc["potrf"][0] if s.factor_lookahead() and s.nu_rows_beside_factor() == 0 else None
+    s.sweep(SETUP_SWEEPS - 6)
     s.sweep(args.warmup)
     ph0 = s.phase_times()
     d0 = s.diagnostics()
@@ -427,6 +434,13 @@ def main():
                 "what": "the whole factorisation with nothing beside it (sweep 2 of the set-up): diagonal-block "
                         "kernels, panel solves, in-panel updates and trailing updates, n^3/3 flop over its span",
                 "ms": potrf_alone_ms, "achieved": ch, "frac": ch / FP64_MFMA_PEAK_TFLOPS}
+        if potrf_ahead_ms:
+            ch = n ** 3 / 3.0 / (potrf_ahead_ms * 1e-3) / 1e12
+            out["roofline"]["cholesky_phase_alone_with_lookahead"] = {
+                "what": "the same with the bulk of each trailing update on a second stream beside the next block "
+                        "columns' steps (sweep 6 of the set-up; the schedule the sampler keeps is named in "
+                        "substeps.potrf)",
+                "ms": potrf_ahead_ms, "achieved": ch, "frac": ch / FP64_MFMA_PEAK_TFLOPS}
         lik = {}
         for label in ("ess_f", "ess_param", "theta_eval_bucket", "theta_table"):
             k = pmc_kernel(rec, label, n, m, world)
