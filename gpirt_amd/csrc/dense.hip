@@ -14,6 +14,14 @@ namespace gpirt {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;        // k-slab depth held in LDS
+// super-tile of the XCD-aware tile order (MODE 4): rows x columns of 128 x 128 tiles that run together on one XCD
+#ifndef GPIRT_NU_ST_R
+#define GPIRT_NU_ST_R 8
+#endif
+#ifndef GPIRT_NU_ST_C
+#define GPIRT_NU_ST_C 4
+#endif
+constexpr int NU_ST_R = GPIRT_NU_ST_R, NU_ST_C = GPIRT_NU_ST_C;
 constexpr int SMALL_GEMM_TILES = 256;   // at most this many 128x128 tiles go to the 64x64-tile kernel
 constexpr int LDS_LD = 144;   // 128 + 16: the four k-rows one ds_read_b64 touches land on
                               // disjoint bank halves
@@ -95,11 +103,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nbm, i
     // and stream the same 8 row panels of A and 4 column panels of B through its L2.
     // Longest K (largest bi) first.
     const int x = t & 7, q = t >> 3;
-    const int sup = (q >> 5) * 8 + x, inner = q & 31;
-    const int nsj = (nbn + 3) / 4;
+    const int sup = (q / (NU_ST_R * NU_ST_C)) * 8 + x, inner = q % (NU_ST_R * NU_ST_C);
+    const int nsj = (nbn + NU_ST_C - 1) / NU_ST_C;
     const int sbi = sup / nsj, sbj = sup % nsj;
-    bi = nbm - 1 - (sbi * 8 + (inner >> 2));
-    bj = sbj * 4 + (inner & 3);
+    bi = nbm - 1 - (sbi * NU_ST_R + inner / NU_ST_C);
+    bj = sbj * NU_ST_C + inner % NU_ST_C;
     if (bi < 0 || bj >= nbn) return;
   } else if (MODE == 2 || MODE == 5) {   // longest K first
     bi = nbm - 1 - t / nbn; bj = t % nbn;
@@ -371,11 +379,11 @@ __device__ __forceinline__ void gemm_direct_tile(const GemmArgs &g, int nbm, int
     bj = t - (int)((int64_t)bi * (bi + 1) / 2);
   } else if (MODE == 4) {   // XCD-aware order, see gemm_f64_kernel
     const int x = t & 7, q = t >> 3;
-    const int sup = (q >> 5) * 8 + x, inner = q & 31;
-    const int nsj = (nbn + 3) / 4;
+    const int sup = (q / (NU_ST_R * NU_ST_C)) * 8 + x, inner = q % (NU_ST_R * NU_ST_C);
+    const int nsj = (nbn + NU_ST_C - 1) / NU_ST_C;
     const int sbi = sup / nsj, sbj = sup % nsj;
-    bi = nbm - 1 - (sbi * 8 + (inner >> 2));
-    bj = sbj * 4 + (inner & 3);
+    bi = nbm - 1 - (sbi * NU_ST_R + inner / NU_ST_C);
+    bj = sbj * NU_ST_C + inner % NU_ST_C;
     if (bi < 0 || bj >= nbn) return;
   } else if (MODE == 2 || MODE == 5) {   // longest K first
     bi = nbm - 1 - t / nbn; bj = t % nbn;
@@ -703,8 +711,8 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
                     a.lda * 4 * 8 < (int64_t)1 << 31 && a.ldb * 80 * 8 < (int64_t)1 << 31 &&
                     ((mode == 1 && BT && tiles > small_lower_tiles()) || (mode == 2 && !BT));
   if (mode == 4) {   // whole 8x4 super-tiles, a multiple of 8 of them (one share per XCD)
-    int64_t nsup = (int64_t)((nbm + 7) / 8) * ((nbn + 3) / 4);
-    tiles = (nsup + 7) / 8 * 8 * 32;
+    int64_t nsup = (int64_t)((nbm + NU_ST_R - 1) / NU_ST_R) * ((nbn + NU_ST_C - 1) / NU_ST_C);
+    tiles = (nsup + 7) / 8 * 8 * NU_ST_R * NU_ST_C;
   }
   // few tiles and a depth that is a multiple of the chunk: the low-latency 64x64 variant.  The
   // late trailing updates of the factorisation (lower tiles only, depth 512) have fewer tiles
