@@ -186,6 +186,7 @@ def main():
     # ranks (exchange staged through host memory); GPIRT_BENCH_COLLECTIVE=torch selects the
     # torch.distributed "nccl" hook instead.
     rehearsal = os.environ.get("GPIRT_BENCH_BACKEND") == "gloo"
+    host_staged = os.environ.get("GPIRT_BENCH_BACKEND") == "host"   # gloo + the library's own HIP runtime, no RCCL
     use_torch_nccl = world > 1 and not rehearsal and os.environ.get("GPIRT_BENCH_COLLECTIVE") == "torch"
     if world > 1 and (rehearsal or use_torch_nccl):
         # torch first: it brings its own copy of the HIP runtime, and a process in which
@@ -197,18 +198,21 @@ def main():
         torch.zeros(1, device="cuda")
 
     from gpirt_amd import _abi, _lib
-    from gpirt_amd.dist import item_range, torch_allreduce
+    from gpirt_amd.dist import host_staged_allreduce, item_range, torch_allreduce
     from gpirt_amd.sampler import Sampler
     from gpirt_amd.synth import generate
 
     lib = _lib.lib()
     if lib.gpirt_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: " + "no HIP device visible")
+    if host_staged:
+        local_rank = local_rank % lib.gpirt_device_count()
     _lib.check(lib.gpirt_set_device(local_rank))
 
     dist = None
     hook = None
     native = None
+    fallback_reason = None
     on_stream = False
     torch_on_gpu = False
     if world > 1:
@@ -224,9 +228,29 @@ def main():
             hook = torch_allreduce(device_buffers=True, on_stream=on_stream)
             torch_on_gpu = True
         else:
-            from gpirt_amd import comm as gcomm
             dist.init_process_group(backend="gloo")
-            native = gcomm.Comm(gcomm.exchange_id(rank, world), rank, world)
+            why = "GPIRT_BENCH_BACKEND=host"
+            if not host_staged:
+                # the communicator is created by all ranks or by none: a rank whose RCCL is missing or
+                # whose bootstrap fails takes every rank to the host-staged hook (a slower line, not none)
+                try:
+                    from gpirt_amd import comm as gcomm
+                    native = gcomm.Comm(gcomm.exchange_id(rank, world), rank, world)
+                except Exception as e:                       # noqa: BLE001
+                    why = "%s: %s" % (type(e).__name__, e)
+                    native = None
+                ok = torch.tensor([1 if native is not None else 0])
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if not int(ok.item()) and native is not None:
+                    native.close()
+                    native = None
+                    why = "another rank could not create its RCCL communicator"
+            if native is None:
+                fallback_reason = why
+                hook = host_staged_allreduce()
+                if rank == 0 and not host_staged:
+                    print("bench.py: no RCCL communicator (%s); the exchange goes through host memory" % why,
+                          file=sys.stderr)
 
     n, m, C = args.n, args.m, args.C
     data = generate(n, m, C, seed=args.seed)          # identical on every rank
@@ -384,7 +408,9 @@ def main():
                        "items_per_gpu": mloc, "parallelism": "items sharded x%d" % world,
                        "collective": ("none" if world == 1 else "libgpirt_rccl.so: ncclAllGather + sum in rank order, "
                                       "stream-ordered" if native is not None else
-                                      "gloo through host memory (rehearsal)" if rehearsal else "torch.distributed nccl")},
+                                      "gloo through host memory (rehearsal)" if rehearsal else
+                                      "gloo through host memory (%s)" % fallback_reason if fallback_reason else
+                                      "torch.distributed nccl")},
             "roofline": {
                 "kernel": ("gemm_direct_lone_kernel<true,1> (rank-512 trailing updates of the blocked Cholesky, lower "
                            "tiles only, on the second stream beside the next block columns' steps: fixed grid, one "

@@ -19,6 +19,7 @@ SYMBOLS = {
     "gpirt_last_error": (C.c_char_p, []),
     "gpirt_device_count": (C.c_int, []),
     "gpirt_set_device": (C.c_int, [C.c_int]),
+    "gpirt_device_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "gpirt_config_defaults": (None, [C.POINTER(_abi.GpirtConfig)]),
     "gpirt_run": (C.c_int, [C.POINTER(_abi.GpirtConfig), _bp, _dp, _dp, _dp, _dp, _dp, _dp,
                             C.POINTER(_abi.GpirtOutputs)]),

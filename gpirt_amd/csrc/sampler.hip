@@ -495,6 +495,13 @@ int gpirt_set_device(int device) {
   return GPIRT_OK;
 }
 
+int gpirt_device_copy(void *dst, const void *src, int64_t bytes, int32_t to_device) {
+  GP_TRY(have_device());
+  if (!dst || !src || bytes < 0) { set_error("gpirt_device_copy: bad argument"); return GPIRT_ERR_BAD_ARG; }
+  GP_HIP(hipMemcpy(dst, src, (size_t)bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+  return GPIRT_OK;
+}
+
 void gpirt_config_defaults(gpirt_config *c) {
   memset(c, 0, sizeof *c);
   c->struct_size = (int32_t)sizeof *c;

@@ -44,6 +44,32 @@ def gather_sum_allreduce(group=None):
     return hook
 
 
+def host_staged_allreduce(group=None):
+    """Hook for DEVICE buffers that needs nothing of torch on the GPU: the vector is copied to the
+    host with the HIP runtime that ``libgpirt_hip.so`` itself uses, summed as the native hook sums
+    it (all-gather over the group, e.g. gloo, then the ranks' vectors added in rank order: the
+    same bits on every rank) and copied back.  Blocking (no ``ALLREDUCE_ON_STREAM``): the sampler
+    drains its stream before it calls.  For ranks that share one GPU in a test, and as the
+    benchmark's fall-back where no RCCL communicator can be created."""
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    copy = _lib.lib().gpirt_device_copy        # the runtime the sampler's buffers live in, whatever torch has loaded
+
+    def hook(ptr, count):
+        mine = np.empty(int(count), dtype=np.float64)
+        if copy(mine.ctypes.data, C.c_void_p(int(ptr)), 8 * int(count), 0):
+            return 1
+        parts = [torch.empty(int(count), dtype=torch.float64) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, torch.from_numpy(mine), group=group)
+        acc = parts[0].numpy().copy()
+        for p in parts[1:]:
+            acc += p.numpy()
+        return 1 if copy(C.c_void_p(int(ptr)), acc.ctypes.data, 8 * int(count), 1) else 0
+
+    return hook
+
+
 def torch_allreduce(group=None, device_buffers=True, via_host=False, on_stream=False):
     """Return ``f(ptr, count) -> 0`` summing `count` doubles at `ptr` over the process group,
     in place.  `device_buffers=True`: `ptr` is HBM on the current device (HIP backend);

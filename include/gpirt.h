@@ -172,6 +172,11 @@ const char *gpirt_last_error(void);
 int gpirt_device_count(void);
 /* Select the device used by every later call on this thread. */
 int gpirt_set_device(int device);
+/* Copy `bytes` between host and device memory with the HIP runtime this library runs on
+ * (to_device = 1: host -> device; 0: device -> host); blocking.  No counterpart in the
+ * reference: for all-reduce hooks that stage the exchange through host memory without a
+ * HIP binding of their own (gpirt_amd/dist.py:host_staged_allreduce). */
+int gpirt_device_copy(void *dst, const void *src, int64_t bytes, int32_t to_device);
 /* Fill `cfg` with the reference's defaults (gpirt-sythetic.R:60-94, utils/model.m:6). */
 void gpirt_config_defaults(gpirt_config *cfg);
 

@@ -18,25 +18,30 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, grid):
+def _worker(rank, world, port, out_dir, grid, torch_free=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if torch_free:
+        # the library first: torch then finds no GPU in this process, and needs none
+        from gpirt_amd import _lib
+        _lib.check(_lib.lib().gpirt_set_device(0))
     import torch
     import torch.distributed as dist
     from gpirt_amd import _abi
-    from gpirt_amd.dist import item_range, torch_allreduce
+    from gpirt_amd.dist import host_staged_allreduce, item_range, torch_allreduce
     from gpirt_amd.sampler import Sampler
     from conftest import load_fixture
 
-    torch.cuda.set_device(0)
+    if not torch_free:
+        torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     d = load_fixture("Wiener_C_5")
     y, theta = _case(d, grid)
     n, m, H = y.shape
     j0, j1 = item_range(m, rank, world)
-    hook = torch_allreduce(device_buffers=True, via_host=True)
+    hook = host_staged_allreduce() if torch_free else torch_allreduce(device_buffers=True, via_host=True)
     cb = _abi.ALLREDUCE_FN(lambda ptr, count, user: hook(ptr, count))
     cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=11, theta_ls=1.5, item_begin=j0, item_end=j1,
                               rank=rank, world=world,
@@ -57,14 +62,16 @@ def _case(d, grid):
     return d["y"][:, :, :k], d["theta"][:, :k]
 
 
-@pytest.mark.parametrize("grid", [0, 1])
-def test_two_ranks_on_one_gpu_match_unsharded_device_chain(tmp_path, grid):
+@pytest.mark.parametrize("grid,torch_free", [(0, False), (1, False), (0, True)])
+def test_two_ranks_on_one_gpu_match_unsharded_device_chain(tmp_path, grid, torch_free):
+    """torch_free: the hook that stages through host memory with the library's own HIP runtime
+    (gpirt_amd.dist.host_staged_allreduce, the benchmark's fall-back when RCCL cannot start)."""
     import torch.multiprocessing as mp
     from gpirt_amd import _abi
     from gpirt_amd.sampler import Sampler
     from conftest import load_fixture
 
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), grid), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), grid, torch_free), nprocs=2, join=True)
     d = load_fixture("Wiener_C_5")
     y, theta = _case(d, grid)
     n, m, H = y.shape
@@ -153,14 +160,17 @@ def test_stream_ordered_rccl_hook_matches_blocking_hook(tmp_path):
     assert open(os.path.join(str(tmp_path), "r.txt")).read() == "ok"
 
 
-def test_bench_runs_with_two_ranks_under_the_launcher(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "host"])
+def test_bench_runs_with_two_ranks_under_the_launcher(tmp_path, backend):
     """bench.py exactly as the multi-GPU runs start it (torch.distributed.run, one process per
     rank), rehearsed on this one-GPU box with both ranks on the same device and gloo carrying
-    the exchange: the multi-rank plumbing (torch before the library, item ranges, the hook,
-    MAX over ranks, one JSON line from rank 0) must work."""
+    the exchange: the multi-rank plumbing (item ranges, the hook, MAX over ranks, one JSON line
+    from rank 0) must work -- with torch's own device tensors ("gloo": torch before the library)
+    and with the library's HIP runtime alone ("host": the path the benchmark falls back to when
+    no RCCL communicator can be created)."""
     import json
     import subprocess
-    env = dict(os.environ, GPIRT_BENCH_BACKEND="gloo")
+    env = dict(os.environ, GPIRT_BENCH_BACKEND=backend)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",

@@ -36,7 +36,7 @@ def main():
     passes = {p: counters(os.path.join(base, p)) for p in ("fetch", "write", "sq", "sq2", "lds") if os.path.isdir(os.path.join(base, p))}
     dur = durations(os.path.join(base, "fetch"))
     report = {"how": "tools/pmc_collect.sh: one rocprofv3 --pmc run per pass (FETCH_SIZE | WRITE_SIZE | 8 SQ + GRBM | 8 SQ | LDS array + VALU + GRBM) of "
-                     "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants` (8 sweeps with the set-up "
+                     "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants` (12 sweeps with the set-up "
                      "sweeps); means per launch; durations are those of the FETCH_SIZE pass (counter collection "
                      "serialises kernels and lowers the clock: compare with the un-profiled kernel_stats)",
               "correction": "HBM bytes = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024 (gfx950 counts a 128-byte read "
