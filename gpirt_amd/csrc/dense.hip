@@ -735,7 +735,10 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
     return GPIRT_OK;
   }
   if (lone) {
-    const dim3 lgrid((unsigned)std::min<int64_t>(tiles, persist_workgroups()));
+    // the rounds the tile list takes with the largest grid, then the smallest grid that needs no more:
+    // the same time, and more CUs left for the kernels beside it
+    const int64_t rounds = (tiles + persist_workgroups() - 1) / persist_workgroups();
+    const dim3 lgrid((unsigned)((tiles + rounds - 1) / rounds));
     if (mode == 1) hipLaunchKernelGGL((gemm_direct_lone_kernel<true, 1>), lgrid, dim3(256), 0, st, a, nbm, nbn, (int)tiles);
     else hipLaunchKernelGGL((gemm_direct_lone_kernel<false, 2>), lgrid, dim3(256), 0, st, a, nbm, nbn, (int)tiles);
     GP_HIP(hipGetLastError());
