@@ -709,7 +709,8 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
   // variant below still takes the launches with few tiles)
   const bool lone = a.lone && a.batch == 1 && !AT && !gemm_lds_only() && pairs_aligned(a) && a.k_base % BK == 0 && a.k_shift % BK == 0 &&
                     a.lda * 4 * 8 < (int64_t)1 << 31 && a.ldb * 80 * 8 < (int64_t)1 << 31 &&
-                    ((mode == 1 && BT && tiles > small_lower_tiles()) || (mode == 2 && !BT));
+                    ((mode == 1 && BT && tiles > small_lower_tiles()) || (mode == 2 && !BT) ||
+                     (mode == 0 && !BT && tiles > SMALL_GEMM_TILES));
   if (mode == 4) {   // whole 8x4 super-tiles, a multiple of 8 of them (one share per XCD)
     int64_t nsup = (int64_t)((nbm + NU_ST_R - 1) / NU_ST_R) * ((nbn + NU_ST_C - 1) / NU_ST_C);
     tiles = (nsup + 7) / 8 * 8 * NU_ST_R * NU_ST_C;
@@ -740,7 +741,8 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
     const int64_t rounds = (tiles + persist_workgroups() - 1) / persist_workgroups();
     const dim3 lgrid((unsigned)((tiles + rounds - 1) / rounds));
     if (mode == 1) hipLaunchKernelGGL((gemm_direct_lone_kernel<true, 1>), lgrid, dim3(256), 0, st, a, nbm, nbn, (int)tiles);
-    else hipLaunchKernelGGL((gemm_direct_lone_kernel<false, 2>), lgrid, dim3(256), 0, st, a, nbm, nbn, (int)tiles);
+    else if (mode == 2) hipLaunchKernelGGL((gemm_direct_lone_kernel<false, 2>), lgrid, dim3(256), 0, st, a, nbm, nbn, (int)tiles);
+    else hipLaunchKernelGGL((gemm_direct_lone_kernel<false, 0>), lgrid, dim3(256), 0, st, a, nbm, nbn, (int)tiles);
     GP_HIP(hipGetLastError());
     return GPIRT_OK;
   }
