@@ -24,6 +24,8 @@ FSTAR_SOLVE = 64
 GENERATOR_PRIOR = 128
 INDEX_TRUNCATE = 512
 NO_NU_OVERLAP = 256
+FIXED_ORDER_SUM = 1024
+SUM_BLOCK = 512
 
 SUMMARY_QUADRATIC, SUMMARY_SKIP_THETA, SUMMARY_DROP_FIRST_THETA = 1, 2, 4
 

@@ -71,8 +71,10 @@ struct ThetaArgs {
   int32_t *gidx, *order;    // [SPEC*n] grid index of the evaluated theta (-1: none), entries by bucket
   int32_t *bstart;          // [G+1] bucket g holds order[bstart[g] .. bstart[g+1])
   int32_t *ghist;           // [G] respondents per grid index, counted by the prepare / decision kernels
-  double *part;             // [nchunks, SPEC*n] partial sums per item chunk
-  int chunk, nchunks;       // items per chunk (multiple of 64), number of chunks
+  double *part;             // [nslots, SPEC*n] partial sums per item chunk
+  int chunk, nchunks;       // items per chunk (multiple of 64), number of this rank's chunks
+  int slot0, nslots;        // `part` holds nslots chunks; this rank's are slot0 .. slot0 + nchunks - 1 (the
+                            // others are those of the other ranks when block sums are exchanged)
   int from_parts;           // the decision kernel sums `part` itself instead of reading `buf`
   int n, H, C, mloc, ML, U_pad, G, constant_irf, R;
   double grid_lo, grid_step;

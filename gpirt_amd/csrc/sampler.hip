@@ -139,6 +139,7 @@ struct gpirt_sampler {
   double *d_part;                  // bucketed evaluation of the table variant (H = 1, else null)
   int32_t *d_gidx, *d_order, *d_bstart, *d_ghist;
   int th_chunk, th_nchunks;
+  int th_slot0, th_nslots;         // GPIRT_FIXED_ORDER_SUM: this rank's first block among all ranks' blocks
   double *d_sum_th, *d_sum_th2, *d_sum_p, *d_sum_arg;   // running sums of the summaries (lazy)
   double *d_nodes, *d_lag;   // Chebyshev nodes on the grid's range and the interpolation matrix
   // low-rank route of the f* step (see setup_fstar_lowrank): barycentric weights, B [R,128],
@@ -663,6 +664,10 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
   }
   s->span_kind[0] = s->span_kind[1] = -1;
   if (cfg->theta_mode == GPIRT_THETA_GRID) {
+    if (cfg->flags & GPIRT_FIXED_ORDER_SUM) {
+      set_error("GPIRT_FIXED_ORDER_SUM is for the slice variant of the respondent step (theta_mode GPIRT_THETA_ESS)");
+      return fail(GPIRT_ERR_BAD_ARG);
+    }
     A_(s->d_onehot, (size_t)C * ML * Np_pad);
     A_(s->d_T, (size_t)G_pad * C * ML);
     A_(s->d_lp, (size_t)G_pad * Np_pad);
@@ -672,10 +677,27 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     const bool table = (cfg->flags & GPIRT_THETA_TABLE) ||
                        (n >= 1024 && !(cfg->flags & GPIRT_THETA_DIRECT));
     if (table) A_(s->d_tab, (size_t)U_pad * C * s->G);
+    const bool fixed = (cfg->flags & GPIRT_FIXED_ORDER_SUM) != 0;
+    if (fixed && !(table && H == 1 && s->G <= THETA_BUCKET_MAX_G)) {
+      set_error("GPIRT_FIXED_ORDER_SUM needs H = 1, the tabulated respondent step and a grid of at most %d points",
+                THETA_BUCKET_MAX_G);
+      return fail(GPIRT_ERR_BAD_ARG);
+    }
     if (table && H == 1 && s->G <= THETA_BUCKET_MAX_G) {
       s->th_chunk = theta_bucket_chunk(C);
+      if (fixed) {
+        // blocks of the WHOLE item set, the same for every number of ranks
+        s->th_chunk = min(s->th_chunk, GPIRT_SUM_BLOCK);
+        if (s->j0 % s->th_chunk || ((s->j0 + mloc) % s->th_chunk && s->j0 + mloc != s->m)) {
+          set_error("GPIRT_FIXED_ORDER_SUM: items [%d, %d) do not begin and end on multiples of %d", s->j0,
+                    s->j0 + mloc, s->th_chunk);
+          return fail(GPIRT_ERR_BAD_ARG);
+        }
+      }
       s->th_nchunks = (mloc + s->th_chunk - 1) / s->th_chunk;
-      A_(s->d_part, (size_t)s->th_nchunks * THETA_SPEC * n);
+      s->th_slot0 = fixed ? s->j0 / s->th_chunk : 0;
+      s->th_nslots = fixed ? (s->m + s->th_chunk - 1) / s->th_chunk : s->th_nchunks;
+      A_(s->d_part, (size_t)s->th_nslots * THETA_SPEC * n);
       A_(s->d_gidx, (size_t)THETA_SPEC * n); A_(s->d_order, (size_t)THETA_SPEC * n); A_(s->d_bstart, (size_t)s->G + 1); A_(s->d_ghist, s->G);
     }
   }
@@ -1296,6 +1318,7 @@ static ThetaArgs theta_args(gpirt_sampler *s) {
   a.part = s->d_part; a.gidx = s->d_gidx; a.order = s->d_order; a.bstart = s->d_bstart;
   a.ghist = s->d_ghist;
   a.chunk = s->th_chunk; a.nchunks = s->th_nchunks;
+  a.slot0 = s->th_slot0; a.nslots = s->th_nslots;
   a.os2 = s->cfg.theta_os > 0 ? s->cfg.theta_os * s->cfg.theta_os : 1.0;
   return a;
 }
@@ -1334,14 +1357,29 @@ static int phase_theta(gpirt_sampler *s) {
   // table variant, H = 1: while a good share of the respondents is active, evaluate them
   // grouped by grid index (each table row is then read once per round)
   int active = s->n;
+  // GPIRT_FIXED_ORDER_SUM with several ranks: every evaluation is the bucketed one, the ranks exchange
+  // the block sums themselves (each rank's blocks in its own slots, zeros in the others': the hook's
+  // sum returns every block exactly) and the decision kernel adds all blocks in item order
+  const bool fixed = (s->cfg.flags & GPIRT_FIXED_ORDER_SUM) && s->cfg.world > 1;
+  const int64_t slot = (int64_t)THETA_SPEC * s->n;
   auto eval = [&](int initial, bool wide) -> int {
-    const bool bucketed = a.part && active * 8 >= s->n;
-    a.from_parts = bucketed && s->cfg.world <= 1;   // read by the decision kernel that follows
+    const bool bucketed = a.part && (fixed || active * 8 >= s->n);
+    a.from_parts = bucketed && (s->cfg.world <= 1 || fixed);   // read by the decision kernel that follows
+    if (fixed) {
+      if (a.slot0 > 0) GP_HIP(hipMemsetAsync(s->d_part, 0, sizeof(double) * (size_t)(slot * a.slot0), s->st));
+      const int after = a.slot0 + a.nchunks;
+      if (after < a.nslots)
+        GP_HIP(hipMemsetAsync(s->d_part + slot * after, 0, sizeof(double) * (size_t)(slot * (a.nslots - after)), s->st));
+    }
     if (bucketed) return launch_theta_eval_bucketed(s->st, a, initial);
     return launch_theta_eval(s->st, a, initial, wide);
   };
+  auto share = [&](int initial) -> int {
+    if (fixed) return exchange(s, s->d_part, slot * a.nslots);
+    return initial ? exchange(s) : exchange(s, s->d_buf, slot);
+  };
   GP_TRY(eval(1, many_items));
-  GP_TRY(exchange(s));
+  GP_TRY(share(1));
   GP_TRY(launch_theta_decide(s->st, a, 0, 0));
   const int max_rounds = (R + THETA_SPEC - 1) / THETA_SPEC + 1;
   std::vector<int> hist((size_t)R + 4, 0);
@@ -1353,7 +1391,7 @@ static int phase_theta(gpirt_sampler *s) {
     const bool wide = many_items || active * 4 <= s->n;
     for (int q = r; q <= last; ++q) {
       GP_TRY(eval(0, wide));
-      GP_TRY(exchange(s, s->d_buf, (int64_t)THETA_SPEC * s->n));
+      GP_TRY(share(0));
       GP_TRY(launch_theta_decide(s->st, a, 1 + (q - 1) * THETA_SPEC, q));
     }
     // one copy into pinned memory brings the status words and the whole history of active counts

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void theta_eval_bucket_kernel(ThetaArgs a) {
       s1 += (yv[t + 1] > 0 && lane + 64 * (t + 1) < cnt) ? v1 : 0.0;
     }
     const double acc = wave_sum(s0 + s1);
-    if (lane == 0) a.part[(int64_t)ch * THETA_SPEC * a.n + i0] = acc;
+    if (lane == 0) a.part[(int64_t)(a.slot0 + ch) * THETA_SPEC * a.n + i0] = acc;
 #pragma unroll
     for (int t = 0; t < PER; ++t) yv[t] = yn[t];
     i0 = i1; i1 = i2;
@@ -316,7 +316,7 @@ __global__ void theta_sum_chunks_kernel(ThetaArgs a, int count) {
   const int64_t V = (int64_t)THETA_SPEC * a.n;
   double s = 0.0;
   if (a.gidx[v] >= 0)
-    for (int ch = 0; ch < a.nchunks; ++ch) s += a.part[V * ch + v];
+    for (int ch = 0; ch < a.nchunks; ++ch) s += a.part[V * (a.slot0 + ch) + v];
   a.buf[v] = s;
 }
 
@@ -366,7 +366,7 @@ __global__ void theta_decide_kernel(ThetaArgs a, int q0, int round) {
     const int64_t v = (int64_t)k * n + i;
     if (!a.from_parts) return a.buf[v];
     double ll = 0.0;         // bucketed evaluation: the chunk partials, summed in fixed order
-    for (int ch = 0; ch < a.nchunks; ++ch) ll += a.part[V * ch + v];
+    for (int ch = 0; ch < a.nslots; ++ch) ll += a.part[V * ch + v];
     return ll;
   };
   auto finish = [&](int q, bool capped) {

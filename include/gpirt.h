@@ -82,10 +82,19 @@ enum {
   GPIRT_GENERATOR_PRIOR = 128, /* keep the Cholesky factor of K(theta,theta) + s2 I in generator
                               (block semiseparable) form instead of as an n x n matrix (see
                               gpirt_sampler_sweep); one IRF group only, ignored otherwise      */
-  GPIRT_INDEX_TRUNCATE = 512  /* look f* up at the grid point at or below theta, the rule of the
+  GPIRT_INDEX_TRUNCATE = 512, /* look f* up at the grid point at or below theta, the rule of the
                               R post-processing (gpirt-sythetic.R:190), instead of at the
                               nearest one (main.m:69, the default)                             */
+  GPIRT_FIXED_ORDER_SUM = 1024 /* respondent slice step with sharded items: exchange the partial
+                              sums of fixed blocks of GPIRT_SUM_BLOCK items (not each rank's
+                              total) and add the blocks in item order on every rank, so that the
+                              chain is the same BIT FOR BIT for every number of ranks, one
+                              included.  Needs H = 1, the tabulated variant (GPIRT_THETA_TABLE or
+                              >= 1024 respondents) and item ranges that begin and end on block
+                              boundaries (or at the last item); refused otherwise.  The hook then
+                              carries ceil(m / GPIRT_SUM_BLOCK) times the doubles per call.      */
 };
+#define GPIRT_SUM_BLOCK 512
 
 /* Sum-all-reduce hook used by the respondent step when items are sharded over
  * ranks: must leave, in place, the element-wise sum over all ranks of `count`

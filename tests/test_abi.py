@@ -60,10 +60,11 @@ def test_flag_values_match_the_header():
     text = open(os.path.join(ROOT, "include", "gpirt.h")).read()
     flags = dict(re.findall(r"\bGPIRT_([A-Z_]+)\s*=\s*(\d+)\s*[,/\n]", text))
     for name in ("RETURN_F", "RETURN_FSTAR", "ALLREDUCE_ON_STREAM", "EXACT_FSTAR", "THETA_TABLE",
-                 "THETA_DIRECT", "FSTAR_SOLVE", "GENERATOR_PRIOR", "NO_NU_OVERLAP"):
+                 "THETA_DIRECT", "FSTAR_SOLVE", "GENERATOR_PRIOR", "NO_NU_OVERLAP", "INDEX_TRUNCATE", "FIXED_ORDER_SUM"):
         assert int(flags[name]) == getattr(_abi, name), name
     values = [getattr(_abi, n) for n in ("RETURN_F", "RETURN_FSTAR", "ALLREDUCE_ON_STREAM", "EXACT_FSTAR",
-                                         "THETA_TABLE", "THETA_DIRECT", "FSTAR_SOLVE", "GENERATOR_PRIOR", "NO_NU_OVERLAP")]
+                                         "THETA_TABLE", "THETA_DIRECT", "FSTAR_SOLVE", "GENERATOR_PRIOR", "NO_NU_OVERLAP",
+                                         "INDEX_TRUNCATE", "FIXED_ORDER_SUM")]
     assert len(set(values)) == len(values) and all(v & (v - 1) == 0 for v in values)   # distinct bits
 
 

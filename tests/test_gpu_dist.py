@@ -246,3 +246,69 @@ def test_native_rccl_collective_without_torch(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_native_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     assert open(os.path.join(str(tmp_path), "native.txt")).read() == "ok"
+
+
+def _fixed_worker(rank, world, port, out_dir):
+    """GPIRT_FIXED_ORDER_SUM: `world` ranks share the GPU (host-staged hook); world = 1 runs unsharded."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from gpirt_amd import _abi, _lib
+    _lib.check(_lib.lib().gpirt_set_device(0))
+    import torch.distributed as dist
+    from gpirt_amd.dist import host_staged_allreduce, item_range
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synth import generate
+
+    n, m, C_ = 1536, 2048, 5
+    d = generate(n, m, C_, seed=4)
+    cfg = _abi.default_config(n=n, m=m, H=1, C=C_, seed=9, flags=_abi.FIXED_ORDER_SUM, rank=rank, world=world)
+    keep = None
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        cfg.item_begin, cfg.item_end = item_range(m, rank, world)
+        hook = host_staged_allreduce()
+        keep = _abi.ALLREDUCE_FN(lambda ptr, count, user: hook(ptr, count))
+        cfg.allreduce = keep
+    with Sampler(cfg, d["y"], theta_init=d["theta"]) as s:
+        s.sweep(3)
+        st = s.state(fstar=False)
+    np.savez(os.path.join(out_dir, "fixed_w%d_r%d.npz" % (world, rank)), j0=cfg.item_begin,
+             j1=cfg.item_end if world > 1 else m, **{k: v for k, v in st.items() if v is not None})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_fixed_order_sum_gives_the_same_bits_for_one_two_and_four_ranks(tmp_path):
+    """GPIRT_FIXED_ORDER_SUM: the respondent step adds the sums of fixed 512-item blocks in item order
+    whatever the sharding, so theta -- and with it every rank's share of f and beta -- is the
+    unsharded chain's bit for bit (1536 respondents, 2048 items: 4 blocks; 1, 2 and 4 ranks)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path)
+    for world in (1, 2, 4):
+        mp.spawn(_fixed_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    full = np.load(os.path.join(out, "fixed_w1_r0.npz"))
+    for world in (2, 4):
+        for r in range(world):
+            p = np.load(os.path.join(out, "fixed_w%d_r%d.npz" % (world, r)))
+            j0, j1 = int(p["j0"]), int(p["j1"])
+            assert np.array_equal(p["theta"], full["theta"]), (world, r)
+            assert np.array_equal(p["f"], full["f"][:, j0:j1]), (world, r)
+            assert np.array_equal(p["beta"], full["beta"][:, j0:j1]), (world, r)
+
+
+def test_fixed_order_sum_refuses_ranges_off_the_block_grid():
+    import ctypes as C
+    from gpirt_amd import _abi, _lib
+    from gpirt_amd.synth import generate
+    n, m = 1536, 2048
+    d = generate(n, m, 5, seed=4)
+    cb = _abi.ALLREDUCE_FN(lambda ptr, count, user: 0)
+    cfg = _abi.default_config(n=n, m=m, H=1, C=5, seed=9, flags=_abi.FIXED_ORDER_SUM, rank=0, world=3,
+                              item_begin=0, item_end=683)
+    cfg.allreduce = cb
+    from gpirt_amd.sampler import Sampler
+    with pytest.raises(_lib.GpirtError) as e:
+        Sampler(cfg, d["y"], theta_init=d["theta"])
+    assert "multiples of 512" in str(e.value)
