@@ -32,7 +32,7 @@ def dense_flops(n, m, G):
     return dict(potrf=n ** 3 / 3.0, nu=float(n) * n * m, fstar=2.0 * n * n * m + 2.0 * G * n * m)
 
 
-def substeps(n, m, C, G, ms, evals, r0=0, lookahead=False):
+def substeps(n, m, C, G, ms, evals, r0=0, lookahead=False, k0=0):
     """Achieved rate of every sub-step of the sweep from its ALGORITHMIC work (the counts of the
     reference's formulation: Cholesky n^3/3, L*Z n^2 m, f* by two triangular solves per item
     2 n^2 m + 2 G n m, a likelihood pass n m cells of 8 B f + 1 B y, an f proposal 17 B/cell)
@@ -45,13 +45,16 @@ def substeps(n, m, C, G, ms, evals, r0=0, lookahead=False):
     fstar_exec = 4.0 * n * 128 * 128 + 2.0 * n * m * 128 + 2.0 * 128 * G * m
     # r0 rows of nu = L*Z are computed on a second stream beside the factorisation: their flop
     # (r0^2 m) fall into the "potrf" span, the launch after it covers rows r0..n
-    fl_beside, fl_after = float(r0) * r0 * m, (float(n) * n - float(r0) * r0) * m
+    # (and the first k0 columns of L's share of the rows r0..n as well: 2 k0 (n - r0) m)
+    fl_tail = 2.0 * k0 * (n - r0) * m
+    fl_beside, fl_after = float(r0) * r0 * m + fl_tail, (float(n) * n - float(r0) * r0) * m - fl_tail
     out = {
         "potrf": {"ms": ms["potrf"], "algorithmic_flop": n ** 3 / 3.0 + fl_beside,
                   "tflops": rate(n ** 3 / 3.0 + fl_beside, ms["potrf"]),
-                  "rows_of_nu_computed_beside_it": r0, "lookahead": lookahead},
+                  "rows_of_nu_computed_beside_it": r0, "columns_of_L_added_to_the_other_rows_beside_it": k0,
+                  "lookahead": lookahead},
         "nu=L*Z": {"ms": ms["nu"], "algorithmic_flop": fl_after, "tflops": rate(fl_after, ms["nu"]),
-                   "rows": [r0, n]},
+                   "rows": [r0, n], "from_column_of_L": k0},
         "fstar": {"ms": ms["fstar"], "algorithmic_flop": 2.0 * n * n * m + 2.0 * G * n * m,
                   "executed_flop": fstar_exec, "tflops_algorithmic": rate(2.0 * n * n * m + 2.0 * G * n * m, ms["fstar"]),
                   "tflops_executed": rate(fstar_exec, ms["fstar"])},
@@ -328,6 +331,7 @@ def main():
     up1 = s.update_times()
     r0 = min(s.nu_rows_beside_factor(), n)
     lookahead = s.factor_lookahead()
+    k0 = min(512 * s.nu_tail_panels(), r0)
     elapsed = max_over_ranks(elapsed)
 
     # The same sweep with the prior factor kept in generator form (GPIRT_GENERATOR_PRIOR): the
@@ -375,13 +379,16 @@ def main():
         rec = pmc_record()
         nu_ms = phases["nu"]
         tiles = -(-n // 128) * -(-mloc // 128)
-        nu_kernel = ("gemm_direct_kernel<false,5> (nu = L*Z, rows %d..%d: one launch per sweep after the "
-                     "factorisation; rows 0..%d run beside the factorisation on a second stream as "
-                     "gemm_direct_kernel<false,2>)" % (r0, n, r0) if r0 > 0 else
+        nu_kernel = ("gemm_direct_kernel<false,5> (nu = L*Z, rows %d..%d, columns of L from %d on: one launch per "
+                     "sweep after the factorisation; rows 0..%d and the earlier columns' share of the other rows run "
+                     "beside the factorisation on a second stream as gemm_direct_lone_kernel<false,2> / <false,0>)"
+                     % (r0, n, k0, r0) if r0 > 0 else
                      "gemm_direct_kernel<false,4> (nu = L*Z, one launch per sweep)" if tiles >= 2048 else
                      "gemm_direct_kernel<false,2> (nu = L*Z, one launch per sweep%s)"
                      % (", K in %d slabs + sum_slabs_kernel" % (8 if tiles < 512 else 4) if tiles < 1024 else ""))
-        fl_launch = (float(n) * n - float(r0) * r0) * mloc      # triangular count of the rows r0..n
+        # triangular count of the rows r0..n, less the first k0 columns of L, whose share those rows
+        # took beside the factorisation
+        fl_launch = (float(n) * n - float(r0) * r0 - 2.0 * k0 * (n - r0)) * mloc
         nu_achieved = fl_launch / (nu_ms * 1e-3) / 1e12 if nu_ms > 0 else 0.0
         upd_ms, upd_n, upd_fl = up1[0] - up0[0], up1[1] - up0[1], up1[2] - up0[2]
         upd_achieved = upd_fl / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
@@ -433,12 +440,12 @@ def main():
                     "nu_after_factorisation": {
                         "kernel": nu_kernel, "achieved": nu_achieved, "frac": nu_achieved / FP64_MFMA_PEAK_TFLOPS,
                         "flop_per_launch": fl_launch, "ms_per_launch": nu_ms,
-                        "algorithmic_bytes_per_launch": 8.0 * ((float(n) * n - float(r0) * r0) / 2 + float(n) * mloc
-                                                               + float(n - r0) * mloc),
+                        "algorithmic_bytes_per_launch": 8.0 * ((float(n) * n - float(r0) * r0) / 2 - float(k0) * (n - r0)
+                                                               + float(n - k0) * mloc + (2.0 if k0 else 1.0) * (n - r0) * mloc),
                         "traffic": nu_pmc["hbm_bytes_per_launch"] if nu_pmc else None},
                 },
             },
-            "substeps": substeps(n, mloc, C, cfg.n_grid, phases, evals, r0, lookahead),
+            "substeps": substeps(n, mloc, C, cfg.n_grid, phases, evals, r0, lookahead, k0),
             "phases_ms": phases,
             "launch_marks_per_step": launches,
             "dense_tflops": (fl["potrf"] + fl["nu"]) / (dense_ms * 1e-3) / 1e12 if dense_ms > 0 else 0.0,

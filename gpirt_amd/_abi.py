@@ -98,7 +98,7 @@ class GpirtOutputs(C.Structure):
         ("jitter_retries", C.c_int32),
         ("nu_rows_beside_factor", C.c_int32),
         ("factor_lookahead", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("nu_tail_panels", C.c_int32),
         ("seconds_total", C.c_double),
     ]
 

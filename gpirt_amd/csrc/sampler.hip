@@ -1548,6 +1548,7 @@ int gpirt_sampler_diagnostics(gpirt_sampler *s, gpirt_outputs *o) {
   o->jitter_retries = s->jitter_retries;
   o->nu_rows_beside_factor = s->gen_now ? 0 : s->nu_rows_done;
   o->factor_lookahead = s->gen_now ? 0 : s->la_now;
+  o->nu_tail_panels = s->gen_now ? 0 : s->nu_tail_done;
   return GPIRT_OK;
 }
 

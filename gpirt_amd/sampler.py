@@ -115,6 +115,13 @@ class Sampler:
         check(lib().gpirt_sampler_diagnostics(self._h, C.byref(o)))
         return int(o.nu_rows_beside_factor)
 
+    def nu_tail_panels(self):
+        """512-column panels of L whose share of the rows after `nu_rows_beside_factor()` was added
+        beside the last sweep's factorisation as well."""
+        o = _abi.GpirtOutputs()
+        check(lib().gpirt_sampler_diagnostics(self._h, C.byref(o)))
+        return int(o.nu_tail_panels)
+
     def factor_lookahead(self):
         """True if the last sweep's factorisation ran its trailing updates on the second stream,
         beside the next block columns' steps."""

@@ -167,7 +167,8 @@ typedef struct gpirt_outputs {
                                     last sweep (0: one launch after it)                    */
   int32_t factor_lookahead;   /* 1: the last sweep's factorisation ran its trailing updates
                                  on the second stream beside the next block columns' steps */
-  int32_t reserved0;
+  int32_t nu_tail_panels;     /* 512-column panels of L whose share of the rows of nu AFTER
+                                 nu_rows_beside_factor was added beside the factorisation too */
   double seconds_total;       /* wall time inside the sweep loop                        */
 } gpirt_outputs;
 
