@@ -167,3 +167,36 @@ def test_rows_of_nu_beside_the_factorisation_leave_the_chain_unchanged(monkeypat
         assert dg == dg0
         for k in ("theta", "f", "beta"):
             assert np.array_equal(base[k], st[k]), (k, flags, forced, ahead)
+
+
+def test_a_failed_factorisation_is_retried_the_same_way_under_every_schedule(monkeypatch):
+    """K(theta, theta) + jitter I with a jitter far too small for near-duplicate inputs: the first
+    attempts hit a non-positive pivot and the sampler retries with ten times the jitter
+    (jitter_retries counts them).  With rows of nu beside the factorisation and with look-ahead, a
+    failed attempt leaves launches on the second stream that still read and write the matrix: the
+    retry must wait for them.  Same chain bit for bit as the plain schedule, same number of retries."""
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synth import generate
+    n, m = 4300, 4096
+    d = generate(n, m, C, seed=2)
+    theta = np.round(d["theta"], 1)                 # ~60 distinct values: the kernel matrix has rank ~60
+
+    def chain(flags, forced, ahead):
+        for name, v in (("GPIRT_NU_OVERLAP", forced), ("GPIRT_LOOKAHEAD", ahead)):
+            if v is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, str(v))
+        cfg = _abi.default_config(n=n, m=m, H=1, C=C, seed=5, flags=flags)
+        cfg.jitter = 1e-15
+        with Sampler(cfg, d["y"], theta_init=theta) as s:
+            s.sweep(2)
+            return s.state(fstar=False), s.diagnostics()
+
+    base, dg0 = chain(_abi.NO_NU_OVERLAP, None, 0)
+    assert dg0["jitter_retries"] > 0
+    for flags, forced, ahead in ((0, 5, 0), (0, 5, 1), (_abi.NO_NU_OVERLAP, None, 1)):
+        st, dg = chain(flags, forced, ahead)
+        assert dg == dg0, (flags, forced, ahead)
+        for k in ("theta", "f", "beta"):
+            assert np.array_equal(base[k], st[k]), (k, flags, forced, ahead)
