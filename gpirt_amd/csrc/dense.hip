@@ -1099,6 +1099,12 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
       p.C = S + (int64_t)oe * TILE * (n_pad + 1); p.ldc = n_pad; p.strideC = sS;
       p.M = (nb - oe) * TILE; p.N = (pe - oe) * TILE; p.K = (oe - o) * TILE; p.batch = 1;
       p.alpha = -1.0; p.beta = 1.0;
+      // The strip and the side stream's share of the update become runnable at the same moment, and
+      // workgroups of the 128 x 128 kernel do not fit beside lone ones: the strip is dispatched first
+      // on the boxes measured (140 us); second, it would crawl on the CUs the fixed grid leaves free
+      // (560 us, seen with another launch order).  On 64 x 64 tiles, which fit either way, it costs
+      // 1-1.5 % of the sweep, so the large strips stay on 128 x 128 tiles; a box where the order
+      // flips loses the schedule's gain, and the sampler's own timing then keeps the plain one.
       GP_TRY(launch_gemm(st, false, true, p));
       continue;
     }
