@@ -353,11 +353,31 @@ constexpr int DNBUF_DEFAULT = GPIRT_DNBUF;   // blocks of fragments held in regi
 #endif
 constexpr int LONE_NBUF = GPIRT_LONE_NBUF;
 
-__device__ __forceinline__ double ld_f64(const double *base, uint32_t off) {
-  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + off);
+// Operand loads of the register-fed kernels go through raw buffer resources: a wave-uniform base
+// (the wave's tile origin, four scalar registers), a fixed 32-bit offset per lane and a scalar
+// offset that advances by a block of k-values.  With plain global loads the compiler rebuilt a
+// 64-bit address per lane and block (a 64-bit scalar multiply for lda * k0, vector adds for the lane
+// offsets: ~30 scalar and 4 vector instructions per 32 MFMAs), and that instruction stream, not the
+// memory system, held the loop at 0.79 of the matrix rate; this form needs 6 scalar instructions a
+// block and reaches 0.92 in the stand-alone loop (tools/sclk_probe.hip: 62.0 -> 72.6 TFLOP/s).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, -1, 0x00020000);   // raw, no bounds below 4 GB
 }
-__device__ __forceinline__ double2 ld_f64x2(const double *base, uint32_t off) {
-  return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + off);
+__device__ __forceinline__ double2 buf_ld_f64x2(rsrc_t r, uint32_t lane_off, uint32_t wave_off) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, wave_off, 0);
+  double2 d;
+  __builtin_memcpy(&d, &v, 16);
+  return d;
+}
+
+__device__ __forceinline__ double buf_ld_f64(rsrc_t r, uint32_t lane_off, uint32_t wave_off) {
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, wave_off, 0);
+  double d;
+  __builtin_memcpy(&d, &v, 8);
+  return d;
 }
 
 // Fragment layout.  An operand whose tile index is contiguous in memory (A always; B when BT) is
@@ -444,15 +464,17 @@ __device__ __forceinline__ void gemm_direct_tile(const GemmArgs &g, int nbm, int
     double fa[DNBUF][2][4];
     double fb[DNBUF][2][4];      // [buffer][step][column tile]
     const int nblk = kend / DKB;
-    auto load = [&](int buf, int blk) {
-      const int k0 = DKB * min(blk, nblk - 1);
-      const double *Ab = Aw + lda * (int64_t)k0;
-      const double *Bb = BT ? Bw + ldb * (int64_t)k0 : Bw + k0;
+    const rsrc_t ra = make_rsrc(Aw), rb = make_rsrc(Bw);
+    const uint32_t stepa = (uint32_t)(lda * (8 * DKB)), stepb = BT ? (uint32_t)(ldb * (8 * DKB)) : 8u * DKB;
+    uint32_t sa = 0, sb = 0;     // byte offsets of the next block to load (scalar registers)
+    int next = 0;                // its number: the blocks are loaded in order, and past the last one
+                                 // the last one is loaded again (its registers are not used)
+    auto load = [&](int buf, int) {
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
-          const double2 v = ld_f64x2(Ab + 32 * gi, oa[s]);
+          const double2 v = buf_ld_f64x2(ra, oa[s] + 256 * gi, sa);
           fa[buf][s][2 * gi] = v.x;
           fa[buf][s][2 * gi + 1] = v.y;
         }
@@ -461,18 +483,22 @@ __device__ __forceinline__ void gemm_direct_tile(const GemmArgs &g, int nbm, int
         for (int s = 0; s < 2; ++s)
 #pragma unroll
           for (int gj = 0; gj < 2; ++gj) {
-            const double2 v = ld_f64x2(Bb + 32 * gj, ob[s]);
+            const double2 v = buf_ld_f64x2(rb, ob[s] + 256 * gj, sb);
             fb[buf][s][2 * gj] = v.x;
             fb[buf][s][2 * gj + 1] = v.y;
           }
       } else {
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
-          const double2 v = ld_f64x2(Bb, ob[tj]);
+          const double2 v = buf_ld_f64x2(rb, ob[tj], sb);
           fb[buf][0][tj] = v.x;
           fb[buf][1][tj] = v.y;
         }
       }
+      ++next;
+      const bool more = next < nblk;
+      sa += more ? stepa : 0u;
+      sb += more ? stepb : 0u;
     };
 #pragma unroll
     for (int p = 0; p < DNBUF - 1; ++p) load(p, p);
@@ -585,27 +611,33 @@ __global__ __launch_bounds__(256) void gemm_direct_small_kernel(GemmArgs g, int 
   constexpr int NB = 4;
   double fa[NB][2][2], fb[NB][2][2];
   const int nblk = g.K / DKB;
-  auto load = [&](int buf, int blk) {
-    const int k0 = DKB * min(blk, nblk - 1);
-    const double *Ab = Aw + lda * (int64_t)k0;
-    const double *Bb = BT ? Bw + ldb * (int64_t)k0 : Bw + k0;
+  // buffer resources and a scalar offset that advances by a block, as in gemm_direct_tile
+  const rsrc_t ra = make_rsrc(Aw), rb = make_rsrc(Bw);
+  const uint32_t stepa = (uint32_t)(lda * (8 * DKB)), stepb = BT ? (uint32_t)(ldb * (8 * DKB)) : 8u * DKB;
+  uint32_t sa = 0, sb = 0;
+  int next = 0;
+  auto load = [&](int buf, int) {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti) fa[buf][s][ti] = ld_f64(Ab + 16 * ti, oa[s]);
+      for (int ti = 0; ti < 2; ++ti) fa[buf][s][ti] = buf_ld_f64(ra, oa[s] + 128 * ti, sa);
     if (BT) {
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) fb[buf][s][tj] = ld_f64(Bb + 16 * tj, ob[s]);
+        for (int tj = 0; tj < 2; ++tj) fb[buf][s][tj] = buf_ld_f64(rb, ob[s] + 128 * tj, sb);
     } else {
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj) {
-        const double2 v = ld_f64x2(Bb, ob[tj]);
+        const double2 v = buf_ld_f64x2(rb, ob[tj], sb);
         fb[buf][0][tj] = v.x;
         fb[buf][1][tj] = v.y;
       }
     }
+    ++next;
+    const bool more = next < nblk;
+    sa += more ? stepa : 0u;
+    sb += more ? stepb : 0u;
   };
   auto mfma_block = [&](int u) {
 #pragma unroll
@@ -682,11 +714,13 @@ static int small_lower_tiles() {
   return v;
 }
 
-// the register-fed kernels take rows in 16-byte pairs: every operand 16-byte aligned, even strides
+// the register-fed kernels take rows in 16-byte pairs: every operand 16-byte aligned, even strides;
+// and their operand loads address a tile's K range with 32-bit byte offsets off the tile's origin
 static bool pairs_aligned(const GemmArgs &a) {
   const uintptr_t p = (uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C;
   const int64_t l = a.lda | a.ldb | a.ldc | a.strideA | a.strideB | a.strideC;
-  return p % 16 == 0 && l % 2 == 0;
+  const int64_t reach = 8 * (std::max(a.lda, a.ldb) * ((int64_t)a.K + 144) + 256);
+  return p % 16 == 0 && l % 2 == 0 && reach < ((int64_t)1 << 32);
 }
 
 // workgroups of a fixed-grid launch: one per CU on 7 of every 8 CUs, so that every shader engine
@@ -725,7 +759,8 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
     if (mode == 1) tiles = (int64_t)nbm * nbn;      // the grid covers the square; tiles above the diagonal exit
     dim3 sgrid((unsigned)(4 * tiles), (unsigned)a.batch), block(256);
     static const bool small_direct = !(getenv("GPIRT_SMALL_DIRECT") && atoi(getenv("GPIRT_SMALL_DIRECT")) == 0);
-    const bool direct_ok = small_direct && !gemm_lds_only() && a.lda * 4 * 8 < (int64_t)1 << 31 && a.ldb * 80 * 8 < (int64_t)1 << 31;
+    const bool direct_ok = small_direct && !gemm_lds_only() && a.lda * 4 * 8 < (int64_t)1 << 31 && a.ldb * 80 * 8 < (int64_t)1 << 31 &&
+                           8 * (std::max(a.lda, a.ldb) * ((int64_t)a.K + 144) + 256) < ((int64_t)1 << 32);
     if (!AT && BT && direct_ok) hipLaunchKernelGGL((gemm_direct_small_kernel<true>), sgrid, block, 0, st, a, 2 * nbn);
     else if (!AT && !BT && direct_ok) hipLaunchKernelGGL((gemm_direct_small_kernel<false>), sgrid, block, 0, st, a, 2 * nbn);
     else if (!AT && BT) hipLaunchKernelGGL((gemm_small_kernel<false, true>), sgrid, block, 0, st, a, 2 * nbn);

@@ -79,6 +79,79 @@ __global__ __launch_bounds__(256, 2) void gemm8(const double *__restrict__ A, co
         make_double2(acc[tj][2 * g][r], acc[tj][2 * g + 1][r]);
 }
 
+// the same loop with the address arithmetic taken out of it: pointers that advance by a block, loads through
+// raw buffer resources (scalar base + 32-bit lane offset), the last blocks drained without prefetch
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ double2 buf_ld(rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  v4u r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+  double2 d; __builtin_memcpy(&d, &r, 16); return d;
+}
+__global__ __launch_bounds__(256, 2) void gemm8p(const double *__restrict__ A, const double *__restrict__ B, double *__restrict__ C,
+                                                  int K, int64_t lda, int64_t ldb, int64_t ldc, int nbn) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lk = lane >> 4;
+  const int bi = blockIdx.x / nbn, bj = blockIdx.x % nbn;
+  const int i0 = bi * 128 + (wave & 1) * 64, j0 = bj * 128 + (wave >> 1) * 64;
+  // resources at the wave's tile; a block of 8 k-values is lda * 64 bytes further in A and 64 bytes further in B
+  const rsrc_t ra = make_rsrc(A + i0), rb = make_rsrc(B + ldb * (int64_t)j0);
+  uint32_t oa[2], ob[4];
+  for (int s = 0; s < 2; ++s) oa[s] = (uint32_t)((2 * lr + lda * (2 * lk + s)) * 8);
+  for (int tj = 0; tj < 4; ++tj) ob[tj] = (uint32_t)((2 * lk + ldb * (16 * tj + lr)) * 8);
+  const uint32_t stepa = (uint32_t)(lda * 64), stepb = 64;
+  v4d acc[4][4];
+  for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0, 0, 0, 0};
+  constexpr int NB = 3;
+  double fa[NB][2][4], fb[NB][2][4];
+  const int nblk = K / 8;
+  uint32_t sa = 0, sb = 0;      // scalar byte offsets of the next block to load
+  int next = 0;                 // its number; past the last block the last one is loaded again
+  auto load = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const double2 v = buf_ld(ra, oa[s] + 256 * g, sa);
+        fa[buf][s][2 * g] = v.x; fa[buf][s][2 * g + 1] = v.y;
+      }
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+      const double2 v = buf_ld(rb, ob[tj], sb);
+      fb[buf][0][tj] = v.x; fb[buf][1][tj] = v.y;
+    }
+    ++next;
+    const bool more = next < nblk;
+    sa += more ? stepa : 0; sb += more ? stepb : 0;
+  };
+  auto mm = [&](int u) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+          acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[u][s][tj], fa[u][s][ti], acc[tj][ti], 0, 0, 0);
+  };
+  load(0); load(1);
+  const int nmain = nblk / NB * NB;
+  for (int blk = 0; blk < nmain; blk += NB)
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      load((u + NB - 1) % NB);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+  for (int u = 0; u < NB - 1; ++u)
+    if (nmain + u < nblk) mm(u);
+  for (int tj = 0; tj < 4; ++tj) for (int g = 0; g < 2; ++g) for (int r = 0; r < 4; ++r)
+    *reinterpret_cast<double2 *>(C + i0 + 32 * g + 2 * lr + ldc * (int64_t)(j0 + 16 * tj + lk + 4 * r)) =
+        make_double2(acc[tj][2 * g][r], acc[tj][2 * g + 1][r]);
+}
+
 int main(int argc, char **argv) {
   const int only = argc > 1 ? atoi(argv[1]) : -1;        // 1 / 2: that load alone, for argv[2] seconds (sample rocm-smi beside it)
   const double seconds = argc > 2 ? atof(argv[2]) : 3.0;
@@ -96,13 +169,14 @@ int main(int argc, char **argv) {
     CK(hipEventRecord(e0, s1));
     for (int q = 0; q < reps; ++q) {
       if (only == 1) hipLaunchKernelGGL(mfma_only, dim3(2048), dim3(256), 0, s1, 13000, C);
+      else if (only == 3) hipLaunchKernelGGL(gemm8p, dim3((M / 128) * (N / 128)), dim3(256), 0, s1, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, N / 128);
       else hipLaunchKernelGGL(gemm8, dim3((M / 128) * (N / 128)), dim3(256), 0, s1, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, N / 128, kmask);
     }
     CK(hipEventRecord(e1, s1));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double flop = (only == 1 ? 4.0 * 2048 * 13000.0 * 16 * 2048 : 2.0 * M * N * K) * reps;
-    printf("%s for %.2f s: %.1f TFLOP/s\n", names[only], ms * 1e-3, flop / (ms * 1e-3) * 1e-12);
+    printf("%s for %.2f s: %.1f TFLOP/s\n", only == 3 ? "GEMM, buffer loads + pointer steps" : names[only], ms * 1e-3, flop / (ms * 1e-3) * 1e-12);
     return 0;
   }
   for (int mode = 0; mode < 3; ++mode)
