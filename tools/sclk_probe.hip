@@ -156,6 +156,11 @@ int main(int argc, char **argv) {
   const int only = argc > 1 ? atoi(argv[1]) : -1;        // 1 / 2: that load alone, for argv[2] seconds (sample rocm-smi beside it)
   const double seconds = argc > 2 ? atof(argv[2]) : 3.0;
   const int kmask = argc > 3 ? atoi(argv[3]) : -1;
+  const int lds = argc > 4 ? atoi(argv[4]) : 0;          // dynamic LDS per workgroup: > 80 KB keeps a CU to one workgroup
+  if (lds > 65536) {
+    CK(hipFuncSetAttribute((const void *)mfma_only, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipFuncSetAttribute((const void *)gemm8p, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  }
   const int M = 9600, N = 4096, K = 4800;
   double *A, *B, *C; long long *out;
   CK(hipMalloc(&A, sizeof(double) * (size_t)M * K)); CK(hipMalloc(&B, sizeof(double) * (size_t)K * N));
@@ -168,8 +173,8 @@ int main(int argc, char **argv) {
     const int reps = (int)(seconds / (only == 1 ? 0.045 : 0.006)) + 1;
     CK(hipEventRecord(e0, s1));
     for (int q = 0; q < reps; ++q) {
-      if (only == 1) hipLaunchKernelGGL(mfma_only, dim3(2048), dim3(256), 0, s1, 13000, C);
-      else if (only == 3) hipLaunchKernelGGL(gemm8p, dim3((M / 128) * (N / 128)), dim3(256), 0, s1, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, N / 128);
+      if (only == 1) hipLaunchKernelGGL(mfma_only, dim3(2048), dim3(256), lds, s1, 13000, C);
+      else if (only == 3) hipLaunchKernelGGL(gemm8p, dim3((M / 128) * (N / 128)), dim3(256), lds, s1, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, N / 128);
       else hipLaunchKernelGGL(gemm8, dim3((M / 128) * (N / 128)), dim3(256), 0, s1, A, B, C, K, (int64_t)M, (int64_t)K, (int64_t)M, N / 128, kmask);
     }
     CK(hipEventRecord(e1, s1));
