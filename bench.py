@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (vendor data sheet; 256 CUs x 128 flop/clk x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
-SETUP_SWEEPS = 9
+SETUP_SWEEPS = 13
 
 
 def dense_flops(n, m, G):
@@ -296,7 +296,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # the sampler times its first sweeps of the dense route (two per schedule, up to four
+    # the sampler times its first sweeps of the dense route (three per schedule, up to four
     # schedules) to choose whether the first rows of nu = L*Z run beside the factorisation and
     # whether the factorisation runs its trailing updates beside the next block columns' steps
     # (same chain bit for bit): that choice is part of the set-up, before the warm-up steps.  Its
@@ -309,14 +309,14 @@ def main():
     alone = s.nu_rows_beside_factor() == 0       # sweep 2 of the set-up runs nothing beside the factorisation
     nu_alone_ms = pb["nu"][0] - pa["nu"][0] if alone else None
     potrf_alone_ms = pb["potrf"][0] - pa["potrf"][0] if alone else None
-    # the sixth set-up sweep (where the sampler has that schedule to offer) is the factorisation with
+    # the eighth set-up sweep (where the sampler has that schedule to offer) is the factorisation with
     # look-ahead and nothing else beside it
-    s.sweep(3)
+    s.sweep(5)
     pc = s.phase_times()
     s.sweep(1)
     pd = s.phase_times()
     potrf_ahead_ms = pd["potrf"][0] - pc["potrf"][0] if s.factor_lookahead() and s.nu_rows_beside_factor() == 0 else None
-    s.sweep(SETUP_SWEEPS - 6)
+    s.sweep(SETUP_SWEEPS - 8)
     s.sweep(args.warmup)
     ph0 = s.phase_times()
     d0 = s.diagnostics()
@@ -471,7 +471,7 @@ def main():
             ch = n ** 3 / 3.0 / (potrf_ahead_ms * 1e-3) / 1e12
             out["roofline"]["cholesky_phase_alone_with_lookahead"] = {
                 "what": "the same with the bulk of each trailing update on a second stream beside the next block "
-                        "columns' steps (sweep 6 of the set-up; the schedule the sampler keeps is named in "
+                        "columns' steps (sweep 8 of the set-up; the schedule the sampler keeps is named in "
                         "substeps.potrf)",
                 "ms": potrf_ahead_ms, "achieved": ch, "frac": ch / FP64_MFMA_PEAK_TFLOPS}
         lik = {}

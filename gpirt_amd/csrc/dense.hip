@@ -741,9 +741,11 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
   int64_t tiles = a.lower_only ? (int64_t)nbm * (nbm + 1) / 2 : (int64_t)nbm * nbn;
   // lone: a fixed grid of at most persist_workgroups() workgroups, one to a CU (the small 64 x 64
   // variant below still takes the launches with few tiles)
-  const bool lone = a.lone && a.batch == 1 && !AT && !gemm_lds_only() && pairs_aligned(a) && a.k_base % BK == 0 && a.k_shift % BK == 0 &&
+  // (the triangular product also in slabs of K side by side, the batch index: the grid's share per slab)
+  const bool lone = a.lone && (a.batch == 1 || ((mode == 2 || mode == 5) && !BT && a.batch <= 16)) && !AT && !gemm_lds_only() &&
+                    pairs_aligned(a) && a.k_base % BK == 0 && a.k_shift % BK == 0 &&
                     a.lda * 4 * 8 < (int64_t)1 << 31 && a.ldb * 80 * 8 < (int64_t)1 << 31 &&
-                    ((mode == 1 && BT && tiles > small_lower_tiles()) || (mode == 2 && !BT) ||
+                    ((mode == 1 && BT && tiles > small_lower_tiles()) || ((mode == 2 || mode == 5) && !BT) ||
                      (mode == 0 && !BT && tiles > SMALL_GEMM_TILES));
   if (mode == 4) {   // whole 8x4 super-tiles, a multiple of 8 of them (one share per XCD)
     int64_t nsup = (int64_t)((nbm + NU_ST_R - 1) / NU_ST_R) * ((nbn + NU_ST_C - 1) / NU_ST_C);
@@ -773,10 +775,11 @@ int launch_gemm(hipStream_t st, bool AT, bool BT, const GemmArgs &a) {
   if (lone) {
     // the rounds the tile list takes with the largest grid, then the smallest grid that needs no more:
     // the same time, and more CUs left for the kernels beside it
-    const int64_t rounds = (tiles + persist_workgroups() - 1) / persist_workgroups();
-    const dim3 lgrid((unsigned)((tiles + rounds - 1) / rounds));
+    const int64_t share = std::max(1, persist_workgroups() / a.batch);
+    const int64_t rounds = (tiles + share - 1) / share;
+    const dim3 lgrid((unsigned)((tiles + rounds - 1) / rounds), (unsigned)a.batch);
     if (mode == 1) hipLaunchKernelGGL((gemm_direct_lone_kernel<true, 1>), lgrid, dim3(256), 0, st, a, nbm, nbn, (int)tiles);
-    else if (mode == 2) hipLaunchKernelGGL((gemm_direct_lone_kernel<false, 2>), lgrid, dim3(256), 0, st, a, nbm, nbn, (int)tiles);
+    else if (mode == 2 || mode == 5) hipLaunchKernelGGL((gemm_direct_lone_kernel<false, 2>), lgrid, dim3(256), 0, st, a, nbm, nbn, (int)tiles);
     else hipLaunchKernelGGL((gemm_direct_lone_kernel<false, 0>), lgrid, dim3(256), 0, st, a, nbm, nbn, (int)tiles);
     GP_HIP(hipGetLastError());
     return GPIRT_OK;

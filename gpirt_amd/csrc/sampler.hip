@@ -193,6 +193,7 @@ struct gpirt_sampler {
   int pref_on_st2;     // this sweep's input-only factors of the low-rank f* step went to the second stream
   int nu_overlap, nu_chunk, nu_rows_done, z_filled;
   int nu_tail;         // super-panels of L whose share of the LAST rows of nu is added beside the factorisation
+  int nu_overlap_la, nu_tail_la;   // the two numbers for the schedules with look-ahead
   int nu_tail_done;    // ... of them, enqueued in this sweep so far
   int ov_now;          // this sweep computes rows of nu beside the factorisation
   int la_now;          // this sweep factors with look-ahead
@@ -201,7 +202,8 @@ struct gpirt_sampler {
   int dense_sweeps;    // sweeps that took the dense route so far
   int span_open;       // parity + 1 of the span this sweep has begun (0: none)
   int span_kind[2];    // the candidate whose span of that parity was measured (-1: none)
-  float sched_ms[4];   // measured span per candidate
+  float sched_ms[4];   // measured span per candidate (the shorter of its two timed sweeps)
+  int span_last[2];    // that span was the candidate's last timed sweep
 };
 
 static void sampler_free(gpirt_sampler *s) {
@@ -604,13 +606,27 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     s->nu_splits = want;
     if (want > 1) A_(s->d_nuparts, (size_t)want * Np_pad * ML);
   }
-  s->nu_overlap = 0;
+  s->nu_overlap = 0; s->nu_overlap_la = 0; s->nu_tail_la = 0;
   // look-ahead in the factorisation: one IRF group, from 4096 inputs on; GPIRT_LOOKAHEAD=0 / 1
   // takes it out of / forces it into the schedule
   const char *la_env = getenv("GPIRT_LOOKAHEAD");
   s->lookahead = P == 1 && Np_pad >= 8 * SUP && !(la_env && atoi(la_env) == 0) ? (la_env ? 2 : 1) : 0;
   s->nu_lone = !(getenv("GPIRT_NU_LONE") && atoi(getenv("GPIRT_NU_LONE")) == 0);
   int ov_forced = 0;
+  if (s->nu_splits > 1 && Np_pad >= 8 * SUP && !(cfg->flags & GPIRT_NO_NU_OVERLAP)) {
+    // nu in slabs of K (few column tiles): the rows of each finished super-panel go to the second stream
+    // as a launch of the same slabs -- same sums, same order of adding them -- on the fixed grid;
+    // GPIRT_NU_OVERLAP=k: the first k super-panels' rows (0: none)
+    const int nsup = inv_nsup(Np_pad);
+    const char *e = getenv("GPIRT_NU_OVERLAP"), *c = getenv("GPIRT_NU_CHUNK");
+    // (measured at n = 10 000 with look-ahead: 512 items 86.4 -> 90.4 sweeps/s, 1024 items 78.0 -> 80.8 with 18 of 20
+    // super-panels in chunks of 12 tile rows; chunks of 4 or 8 tile rows cost the factorisation more than they save)
+    s->nu_overlap = max(0, min(e ? atoi(e) : (9 * nsup) / 10, nsup));
+    ov_forced = e != nullptr;
+    s->nu_chunk = c ? max(1, atoi(c)) : 12;
+    s->nu_tail = 0;
+    s->nu_overlap_la = s->nu_overlap; s->nu_tail_la = 0;
+  }
   if (s->nu_splits == 1 && Np_pad >= 8 * SUP && !(cfg->flags & GPIRT_NO_NU_OVERLAP)) {
     // GPIRT_NU_OVERLAP=k forces k super-panels (0: none) and GPIRT_NU_CHUNK=t the chunk size;
     // by default the rows left for the launch after the factorisation make at most 512 tiles
@@ -633,6 +649,12 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     // (all panels before the last overlapped super-panel by default; measured at n = 10 000, m = 4096:
     // 51.8 -> 53.7 sweeps/s with 15 super-panels of rows and 14 panels, the factor + nu span 14.7 -> 14.1 ms)
     s->nu_tail = s->nu_overlap > 0 ? max(0, min(tl ? atoi(tl) : s->nu_overlap - 1, s->nu_overlap - 1)) : 0;
+    // With look-ahead the second stream carries the bulk of every trailing update already: there the
+    // panels' shares of the last rows cost more than they give, and more rows beside the late,
+    // emptier chain phases are better (n = 10 000, 2048 items: 11 super-panels + 10 panels 64.2, 16-17
+    // super-panels + none 68.6 sweeps/s, look-ahead alone 67.0)
+    s->nu_overlap_la = e ? s->nu_overlap : min(nsup, max(s->nu_overlap, (17 * nsup) / 20));
+    s->nu_tail_la = tl ? s->nu_tail : 0;
   }
   // the schedules this sampler may use, plainest first
   s->sched_ncand = 0;
@@ -650,7 +672,7 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
               hipEventCreateWithFlags(&s->ev_pref, hipEventDisableTiming) == hipSuccess;
     for (int a = 0; a < 2 && ok; ++a)
       for (int b = 0; b < 2 && ok; ++b) ok = hipEventCreate(&s->ev_span[a][b]) == hipSuccess;
-    for (int i = 0; i < s->nu_overlap && ok; ++i) {
+    for (int i = 0; i < max(s->nu_overlap, s->nu_overlap_la) && ok; ++i) {
       hipEvent_t ev;
       ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
       if (ok) s->ev_panel.push_back(ev);
@@ -663,6 +685,7 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     if (!ok) { set_error("second stream: creation failed"); return fail(GPIRT_ERR_HIP); }
   }
   s->span_kind[0] = s->span_kind[1] = -1;
+  for (int c = 0; c < 4; ++c) s->sched_ms[c] = 1e30f;
   if (cfg->theta_mode == GPIRT_THETA_GRID) {
     if (cfg->flags & GPIRT_FIXED_ORDER_SUM) {
       set_error("GPIRT_FIXED_ORDER_SUM is for the slice variant of the respondent step (theta_mode GPIRT_THETA_ESS)");
@@ -908,12 +931,29 @@ static GemmArgs nu_args(const gpirt_sampler *s, int r0, int r1) {
   return g;
 }
 
+// The same rows with K cut into nu_splits slabs that run side by side (the GEMM's batch index), each
+// into its own copy of nu; launch_sum_slabs adds the copies in slab order.  Slabs that begin at or
+// beyond row r1 hold nothing for these rows and are left out (adding their zeros changes no bit).
+static int nu_split_launch(gpirt_sampler *s, hipStream_t q, int r0, int r1, int lone) {
+  if (r1 <= r0) return GPIRT_OK;
+  GemmArgs g = nu_args(s, r0, r1);
+  const int kc = s->Np_pad / s->nu_splits, nsl = min(s->nu_splits, (r1 + kc - 1) / kc);
+  g.K = kc; g.k_shift = kc; g.batch = nsl;
+  g.strideA = (int64_t)kc * s->Np_pad; g.strideB = kc;
+  g.C = s->d_nuparts + r0;
+  g.k_trim = r0 > 0 || r1 < s->Np_pad ? 4 : 1;   // (a kernel name of its own in a profile)
+  g.lone = lone;
+  GP_TRY(launch_gemm(q, false, false, g));
+  return launch_sum_slabs(q, s->d_nuparts + r0, nsl, g.strideC, r1 - r0, s->ML, s->Np_pad, s->d_nu + r0, s->Np_pad);
+}
+
 // Called by the factorisation when block columns [o, oe) are final and the trailing update
 // behind them is enqueued: whole chunks of final rows go to the second stream.
 static int nu_panel_hook(void *ctx, int o, int oe) {
   gpirt_sampler *s = (gpirt_sampler *)ctx;
-  const int sp = o / 4, lim = min(s->nu_overlap * 4, s->nb);
-  if (sp >= s->nu_overlap) return GPIRT_OK;
+  const int nov = s->la_now ? s->nu_overlap_la : s->nu_overlap, ntail = s->la_now ? s->nu_tail_la : s->nu_tail;
+  const int sp = o / 4, lim = min(nov * 4, s->nb);
+  if (sp >= nov) return GPIRT_OK;
   const int avail = min(oe, lim);
   bool recorded = false;
   for (int t = s->nu_rows_done / TILE; t + s->nu_chunk <= avail || (avail == lim && t < lim);) {
@@ -923,13 +963,17 @@ static int nu_panel_hook(void *ctx, int o, int oe) {
       GP_HIP(hipStreamWaitEvent(s->st2, s->ev_panel[sp], 0));
       recorded = true;
     }
-    GemmArgs c = nu_args(s, t * TILE, t1 * TILE);
-    c.lone = s->nu_lone;
-    GP_TRY(launch_gemm(s->st2, false, false, c));
+    if (s->nu_splits > 1) {
+      GP_TRY(nu_split_launch(s, s->st2, t * TILE, t1 * TILE, s->nu_lone));
+    } else {
+      GemmArgs c = nu_args(s, t * TILE, t1 * TILE);
+      c.lone = s->nu_lone;
+      GP_TRY(launch_gemm(s->st2, false, false, c));
+    }
     s->nu_rows_done = t1 * TILE;
     t = t1;
   }
-  if (sp < s->nu_tail && sp == s->nu_tail_done && lim < s->nb) {
+  if (sp < ntail && sp == s->nu_tail_done && lim < s->nb) {
     if (!recorded) {
       GP_HIP(hipEventRecord(s->ev_panel[sp], s->st));
       GP_HIP(hipStreamWaitEvent(s->st2, s->ev_panel[sp], 0));
@@ -947,23 +991,30 @@ static int nu_panel_hook(void *ctx, int o, int oe) {
   return GPIRT_OK;
 }
 
-// The span measured in the sweep before this one is complete once this sweep's factorisation
-// has been waited for.  Candidate c runs in the dense route's sweeps 2c (warming up) and 2c + 1
-// (timed); once every candidate has its time the fastest stays, a plainer one unless the other is
-// 2 % faster.
+// The sweep before this one is measured from the begin of its factorisation to the begin of this
+// sweep's, which has been waited for by now.  Candidate c runs in the dense route's sweeps 3c (warming up), 3c + 1 and
+// 3c + 2 (timed, the shorter span counts: one timed sweep per candidate let a box's jitter pick);
+// once every candidate has its time the fastest stays, a plainer one unless the other is 1 % faster.
+constexpr int SCHED_SWEEPS = 3;
 static int schedule_tune(gpirt_sampler *s) {
   if (s->sched_choice >= 0) return GPIRT_OK;
   const int prev = (s->dense_sweeps + 1) & 1, kind = s->span_kind[prev];
   if (kind >= 0) {
     float ms = 0;
-    GP_HIP(hipEventElapsedTime(&ms, s->ev_span[prev][0], s->ev_span[prev][1]));
-    s->sched_ms[kind] = ms;
+    // the whole sweep, from its factorisation's begin to this sweep's: what runs beside the factorisation
+    // also moves the phases after it (the input-only factors of the f* step on the second stream)
+    GP_HIP(hipEventElapsedTime(&ms, s->ev_span[prev][0], s->ev_span[s->dense_sweeps & 1][0]));
+    s->sched_ms[kind] = fminf(s->sched_ms[kind], ms);
     s->span_kind[prev] = -1;
-    if (kind == s->sched_ncand - 1) {
+    if (kind == s->sched_ncand - 1 && s->span_last[prev]) {
       int best = 0;
       for (int c = 1; c < s->sched_ncand; ++c)
-        if (s->sched_ms[c] < 0.98f * s->sched_ms[best]) best = c;
+        if (s->sched_ms[c] < 0.99f * s->sched_ms[best]) best = c;
       s->sched_choice = s->sched_cand[best];
+      if (getenv("GPIRT_SCHED_DEBUG"))
+        for (int c = 0; c < s->sched_ncand; ++c)
+          fprintf(stderr, "gpirt schedule %d (rows of nu beside %d, look-ahead %d): %.3f ms%s\n", s->sched_cand[c],
+                  s->sched_cand[c] & 1, (s->sched_cand[c] >> 1) & 1, s->sched_ms[c], c == best ? "  <- kept" : "");
     }
   }
   return GPIRT_OK;
@@ -993,10 +1044,11 @@ static int phase_factor(gpirt_sampler *s) {
   const int par = s->dense_sweeps & 1;
   int sched = s->sched_choice;
   if (sched < 0) {
-    const int ci = min(s->dense_sweeps / 2, s->sched_ncand - 1);
+    const int ci = min(s->dense_sweeps / SCHED_SWEEPS, s->sched_ncand - 1);
     sched = s->sched_cand[ci];
     GP_HIP(hipEventRecord(s->ev_span[par][0], s->st));
-    s->span_kind[par] = (s->dense_sweeps & 1) && s->dense_sweeps / 2 < s->sched_ncand ? ci : -1;
+    s->span_kind[par] = s->dense_sweeps % SCHED_SWEEPS >= 1 && s->dense_sweeps / SCHED_SWEEPS < s->sched_ncand ? ci : -1;
+    s->span_last[par] = s->dense_sweeps % SCHED_SWEEPS == SCHED_SWEEPS - 1;
     s->span_open = par + 1;
   }
   s->ov_now = sched & 1;
@@ -1097,13 +1149,7 @@ static int phase_f(gpirt_sampler *s) {
     GP_TRY(launch_gemm(s->st, false, false, u));
   } else if (s->nu_splits > 1) {
     // the slabs of K run side by side and a small kernel adds them in fixed order
-    const int kc = s->Np_pad / s->nu_splits;
-    g.K = kc; g.k_shift = kc; g.batch = s->nu_splits;
-    g.strideA = (int64_t)kc * s->Np_pad; g.strideB = kc;
-    g.C = s->d_nuparts;
-    GP_TRY(launch_gemm(s->st, false, false, g));
-    GP_TRY(launch_sum_slabs(s->st, s->d_nuparts, s->nu_splits, g.strideC, s->Np_pad, s->ML, s->Np_pad,
-                            s->d_nu, s->Np_pad));
+    GP_TRY(nu_split_launch(s, s->st, r0, s->Np_pad, 0));
   } else {
     GP_TRY(launch_gemm(s->st, false, false, g));
   }

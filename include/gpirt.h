@@ -79,7 +79,7 @@ enum {
                               from 4096 inputs on, the first rows of it are computed beside the
                               factorisation on a second stream (same result bit for bit) when the
                               sampler's own timing of its first sweeps finds that faster (it
-                              times up to four schedules, two sweeps each; the flag takes the
+                              times up to four schedules, three sweeps each; the flag takes the
                               two with rows of nu beside the factorisation out of the choice)   */
   GPIRT_GENERATOR_PRIOR = 128, /* keep the Cholesky factor of K(theta,theta) + s2 I in generator
                               (block semiseparable) form instead of as an n x n matrix (see

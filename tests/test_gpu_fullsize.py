@@ -169,6 +169,41 @@ def test_rows_of_nu_beside_the_factorisation_leave_the_chain_unchanged(monkeypat
             assert np.array_equal(base[k], st[k]), (k, flags, forced, ahead)
 
 
+def test_slabs_of_nu_beside_the_factorisation_leave_the_chain_unchanged(monkeypatch):
+    """With a rank's share of the items nu = L Z has few column tiles and its K range runs in slabs side
+    by side, added in slab order.  The rows of finished super-panels are computed that way too, beside the
+    factorisation (same slabs, same order; slabs that hold nothing for those rows are left out): four
+    sweeps give the same chain bit for bit with 12 or all 20 super-panels' rows forced there, with and
+    without look-ahead, with the sampler's own choice, and with everything behind the factorisation."""
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synth import generate
+    m = 512
+    d = generate(N, m, C, seed=4)
+
+    def chain(flags, forced, ahead):
+        for name, v in (("GPIRT_NU_OVERLAP", forced), ("GPIRT_LOOKAHEAD", ahead)):
+            if v is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, str(v))
+        cfg = _abi.default_config(n=N, m=m, H=1, C=C, seed=6, flags=flags)
+        with Sampler(cfg, d["y"], theta_init=d["theta"]) as s:
+            s.sweep(4)
+            return s.state(fstar=False), s.nu_rows_beside_factor(), s.factor_lookahead(), s.diagnostics()
+
+    base, rows0, la0, dg0 = chain(_abi.NO_NU_OVERLAP, None, 0)
+    assert rows0 == 0 and not la0
+    for flags, forced, ahead, rows_ok, la_ok in ((0, 12, 0, (12 * 512,), (False,)),
+                                                 (0, 12, 1, (12 * 512,), (True,)),
+                                                 (0, 20, 1, ((N + 127) // 128 * 128,), (True,)),
+                                                 (0, None, None, (0, 18 * 512), (False, True))):
+        st, rows, la, dg = chain(flags, forced, ahead)
+        assert rows in rows_ok and la in la_ok, (flags, forced, ahead, rows, la)
+        assert dg == dg0
+        for k in ("theta", "f", "beta"):
+            assert np.array_equal(base[k], st[k]), (k, flags, forced, ahead)
+
+
 def test_a_failed_factorisation_is_retried_the_same_way_under_every_schedule(monkeypatch):
     """K(theta, theta) + jitter I with a jitter far too small for near-duplicate inputs: the first
     attempts hit a non-positive pivot and the sampler retries with ten times the jitter

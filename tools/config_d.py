@@ -17,7 +17,7 @@ cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=1, theta_os=1.0, theta_ls=12.
 bps = np.full((3, m), 3.0); bps[0] = 0.0; bps[2] = 0.0
 tps = np.ones((2, n)); tps[1] = 0.0
 s = Sampler(cfg, y, theta_init=standardised_row_scores(y), beta_prior_sds=bps, theta_prior_sds=tps)
-s.sweep(6)      # the sampler settles its schedule in its first sweeps
+s.sweep(13)     # the sampler settles its schedule in its first sweeps
 p0 = s.phase_times()
 t0 = time.perf_counter()
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 10
