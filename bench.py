@@ -234,20 +234,11 @@ def main():
             dist.init_process_group(backend="gloo")
             why = "GPIRT_BENCH_BACKEND=host"
             if not host_staged:
-                # the communicator is created by all ranks or by none: a rank whose RCCL is missing or
-                # whose bootstrap fails takes every rank to the host-staged hook (a slower line, not none)
-                try:
-                    from gpirt_amd import comm as gcomm
-                    native = gcomm.Comm(gcomm.exchange_id(rank, world), rank, world)
-                except Exception as e:                       # noqa: BLE001
-                    why = "%s: %s" % (type(e).__name__, e)
-                    native = None
-                ok = torch.tensor([1 if native is not None else 0])
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if not int(ok.item()) and native is not None:
-                    native.close()
-                    native = None
-                    why = "another rank could not create its RCCL communicator"
+                # the communicator is created by all ranks or by none (the ranks vote over gloo before
+                # RCCL's own bootstrap, which is a collective): a rank whose RCCL is missing or whose
+                # bootstrap fails takes every rank to the host-staged hook (a slower line, not none)
+                from gpirt_amd import comm as gcomm
+                native, why = gcomm.create_all_or_none(rank, world)
             if native is None:
                 fallback_reason = why
                 hook = host_staged_allreduce()
@@ -321,11 +312,13 @@ def main():
     ph0 = s.phase_times()
     d0 = s.diagnostics()
     up0 = s.update_times()
+    calls0 = native.calls() if native is not None else 0
     barrier()
     t0 = time.perf_counter()
     s.sweep(args.steps)                  # drains its stream before returning
     barrier()
     elapsed = time.perf_counter() - t0
+    calls1 = native.calls() if native is not None else 0
     ph1 = s.phase_times()
     d1 = s.diagnostics()
     up1 = s.update_times()
@@ -417,7 +410,11 @@ def main():
                                       "stream-ordered" if native is not None else
                                       "gloo through host memory (rehearsal)" if rehearsal else
                                       "gloo through host memory (%s)" % fallback_reason if fallback_reason else
-                                      "torch.distributed nccl")},
+                                      "torch.distributed nccl"),
+                       # what RCCL itself says about the communicator (ncclCommCount), and how often a sweep used it
+                       "collective_world": native.world_reported() if native is not None else None,
+                       "collective_calls_per_step": (calls1 - calls0) / args.steps if native is not None else None,
+                       "collective_doubles_per_call_max": native.capacity() if native is not None else None},
             "roofline": {
                 "kernel": ("gemm_direct_lone_kernel<true,1> (rank-512 trailing updates of the blocked Cholesky, lower "
                            "tiles only, on the second stream beside the next block columns' steps: fixed grid, one "

@@ -30,6 +30,7 @@ SYMBOLS = {
     "gpirt_sampler_phase_times": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_int64)]),
     "gpirt_sampler_update_times": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_int64), _dp]),
     "gpirt_sampler_diagnostics": (C.c_int, [C.c_void_p, C.POINTER(_abi.GpirtOutputs)]),
+    "gpirt_sampler_ll_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "gpirt_sampler_accumulate": (C.c_int, [C.c_void_p, C.c_int32]),
     "gpirt_sampler_summary": (C.c_int, [C.c_void_p, C.POINTER(_abi.GpirtSummary)]),
     "gpirt_run_summary": (C.c_int, [C.POINTER(_abi.GpirtConfig), _bp, _dp, _dp, _dp, _dp, _dp, _dp,

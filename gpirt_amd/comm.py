@@ -21,6 +21,8 @@ SYMBOLS = {
     "gpirt_comm_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gpirt_comm_allreduce": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "gpirt_comm_calls": (C.c_int64, [C.c_void_p]),
+    "gpirt_comm_world": (C.c_int, [C.c_void_p]),
+    "gpirt_comm_capacity": (C.c_int64, [C.c_void_p]),
     "gpirt_comm_destroy": (None, [C.c_void_p]),
 }
 
@@ -75,6 +77,44 @@ def exchange_id(rank, world, key="gpirt_comm_id"):
     return bytes(store.get(key))
 
 
+def create_all_or_none(rank, world):
+    """The communicator on every rank of an initialised torch.distributed (CPU) group, or on none.
+
+    ncclCommInitRank is itself a collective: a rank that cannot even load the library, or rank 0
+    failing to create the identifier, would leave the others waiting inside the bootstrap.  So the
+    ranks vote BEFORE it -- each loads the library, rank 0 creates the identifier, all-reduce(MIN)
+    of the outcome -- and only a unanimous vote goes on; the identifier then travels through the
+    same group (no second store, no second port).  A second vote behind the creation lets a rank
+    whose RCCL returned an error take every rank to the fallback.  Returns (comm or None, reason)."""
+    import torch
+    import torch.distributed as dist
+    uid, why = None, None
+    try:
+        lib()
+        if rank == 0:
+            uid = unique_id()
+    except Exception as e:                               # noqa: BLE001
+        why = "%s: %s" % (type(e).__name__, e)
+    ok = torch.tensor([0 if why else 1])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if not int(ok.item()):
+        return None, why or "another rank could not load libgpirt_rccl.so or create the identifier"
+    box = [uid]
+    dist.broadcast_object_list(box, src=0)
+    comm = None
+    try:
+        comm = Comm(box[0], rank, world)
+    except Exception as e:                               # noqa: BLE001
+        why = "%s: %s" % (type(e).__name__, e)
+    ok = torch.tensor([1 if comm is not None else 0])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if not int(ok.item()):
+        if comm is not None:
+            comm.close()
+        return None, why or "another rank could not create its RCCL communicator"
+    return comm, None
+
+
 class Comm:
     """One rank of the communicator, created on the CURRENT device."""
 
@@ -96,6 +136,14 @@ class Comm:
 
     def calls(self):
         return int(lib().gpirt_comm_calls(self._h))
+
+    def world_reported(self):
+        """Ranks in the communicator as RCCL counts them (ncclCommCount)."""
+        return int(lib().gpirt_comm_world(self._h))
+
+    def capacity(self):
+        """Doubles per rank the all-gather's staging holds."""
+        return int(lib().gpirt_comm_capacity(self._h))
 
     def close(self):
         if self._h:

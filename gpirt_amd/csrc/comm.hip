@@ -101,6 +101,20 @@ int gpirt_comm_set_stream(gpirt_comm *c, void *stream) {
   return GPIRT_OK;
 }
 
+// room for `count` doubles per rank in the all-gather's staging
+static int comm_reserve(gpirt_comm *c, int64_t count) {
+  if (count <= c->capacity) return GPIRT_OK;
+  CM_HIP(hipSetDevice(c->device));
+  // what is in flight on the stream may still read the old staging
+  if (c->have_stream) CM_HIP(hipStreamSynchronize(c->stream));
+  if (c->gather) CM_HIP(hipFree(c->gather));
+  c->gather = nullptr;
+  c->capacity = 0;
+  CM_HIP(hipMalloc((void **)&c->gather, sizeof(double) * (size_t)count * c->world));
+  c->capacity = count;
+  return GPIRT_OK;
+}
+
 int gpirt_comm_allreduce(double *d_buf, int64_t count, void *user) {
   gpirt_comm *c = (gpirt_comm *)user;
   if (!c || !d_buf || count < 1) { comm_error("gpirt_comm_allreduce: bad argument"); return GPIRT_ERR_BAD_ARG; }
@@ -110,15 +124,12 @@ int gpirt_comm_allreduce(double *d_buf, int64_t count, void *user) {
     return GPIRT_ERR_BAD_ARG;
   }
   CM_HIP(hipSetDevice(c->device));
+  // gpirt_comm_bind sized the staging for the sampler's largest exchange; a caller that binds the hook by
+  // hand (or changes the configuration after binding) still gets a staging that grows, at the price of a
+  // stream drain and an allocation inside the sweep
   if (count > c->capacity) {
-    // the staging grows to the largest vector seen (the round of four proposals per respondent);
-    // what is in flight on the stream may still read the old one
-    CM_HIP(hipStreamSynchronize(c->stream));
-    if (c->gather) CM_HIP(hipFree(c->gather));
-    c->gather = nullptr;
-    c->capacity = 0;
-    CM_HIP(hipMalloc((void **)&c->gather, sizeof(double) * (size_t)count * c->world));
-    c->capacity = count;
+    const int rc = comm_reserve(c, count);
+    if (rc != GPIRT_OK) return rc;
   }
   CM_NCCL(ncclAllGather(d_buf, c->gather, (size_t)count, ncclDouble, c->nccl, c->stream));
   hipLaunchKernelGGL(sum_ranks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream,
@@ -135,10 +146,31 @@ int gpirt_comm_bind(gpirt_comm *c, gpirt_config *cfg) {
   cfg->allreduce = gpirt_comm_allreduce;
   cfg->allreduce_user = c;
   cfg->flags |= GPIRT_ALLREDUCE_ON_STREAM;
-  return GPIRT_OK;
+  // the largest vector a sweep of this configuration exchanges, so that no call inside a sweep allocates:
+  // four proposals per respondent and round; with GPIRT_FIXED_ORDER_SUM one such vector per block of items
+  // (the blocks of the bucketed evaluation, at most GPIRT_SUM_BLOCK items); the static respondent step
+  // exchanges the padded grid x respondents table
+  int64_t count = 4 * (int64_t)cfg->n;
+  if (cfg->flags & GPIRT_FIXED_ORDER_SUM) {
+    const int C = cfg->C > 0 ? cfg->C : 2;
+    int chunk = (6144 / C) & ~63;
+    chunk = chunk < 64 ? 64 : (chunk > GPIRT_SUM_BLOCK ? GPIRT_SUM_BLOCK : chunk);
+    count *= (cfg->m + chunk - 1) / chunk;
+  }
+  if (cfg->theta_mode == GPIRT_THETA_GRID) count = (int64_t)((cfg->n_grid + 127) / 128 * 128) * cfg->n;
+  return comm_reserve(c, count);
 }
 
 int64_t gpirt_comm_calls(const gpirt_comm *c) { return c ? c->calls : 0; }
+
+int gpirt_comm_world(const gpirt_comm *c) {
+  if (!c) return 0;
+  int count = 0;
+  if (ncclCommCount(c->nccl, &count) != ncclSuccess) return 0;
+  return count;
+}
+
+int64_t gpirt_comm_capacity(const gpirt_comm *c) { return c ? c->capacity : 0; }
 
 void gpirt_comm_destroy(gpirt_comm *c) {
   if (!c) return;

@@ -84,6 +84,9 @@ struct ThetaArgs {
   int32_t *remaining;       // [R+4] respondents still active after the decision of round r; the last
                             // entry: largest proposal number at which a respondent finished
   unsigned long long *counters;  // [1] capped
+  unsigned long long *ll_seen;   // optional: wrapping sum over every log-likelihood sum a decision read of
+                                 // (its bit pattern) x (2 entry + 1): equal chains of decisions on equal bits
+                                 // give equal words whatever the order of the atomics
 };
 // Proposals per lock-step round.  After a rejection the next angle is a function of the
 // bracket and the generator alone, so a round draws each respondent's next THETA_SPEC

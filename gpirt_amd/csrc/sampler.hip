@@ -160,7 +160,7 @@ struct gpirt_sampler {
   int summary_draws, summary_theta_draws;
   int32_t *d_done, *d_info, *d_remaining;   // d_remaining = d_info + 4: one block, one copy per look
   int32_t *h_look;                           // pinned host mirror of that block
-  unsigned long long *d_counters;  // [3][2]: f, param, theta x (evaluations, capped)
+  unsigned long long *d_counters;  // [3][2]: f, param, theta x (evaluations, capped); [6] see ThetaArgs::ll_seen
   int64_t theta_rounds;
   int jitter_retries;
   double phase_ms[PH_COUNT];
@@ -189,7 +189,7 @@ struct gpirt_sampler {
   int nu_lone;         // the chunks of nu beside the factorisation run one workgroup to a CU
   std::vector<hipEvent_t> ev_ahead;
   std::vector<hipEvent_t> ev_panel;
-  hipEvent_t ev_join, ev_z, ev_pref, ev_span[2][2];   // [sweep parity][begin, end] of the factor + nu span
+  hipEvent_t ev_join, ev_z, ev_pref, ev_tail, ev_span[2][2];   // [sweep parity][begin, end] of the factor + nu span
   int pref_on_st2;     // this sweep's input-only factors of the low-rank f* step went to the second stream
   int nu_overlap, nu_chunk, nu_rows_done, z_filled;
   int nu_tail;         // super-panels of L whose share of the LAST rows of nu is added beside the factorisation
@@ -226,6 +226,7 @@ static void sampler_free(gpirt_sampler *s) {
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->ev_z) (void)hipEventDestroy(s->ev_z);
   if (s->ev_pref) (void)hipEventDestroy(s->ev_pref);
+  if (s->ev_tail) (void)hipEventDestroy(s->ev_tail);
   for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) if (s->ev_span[a][b]) (void)hipEventDestroy(s->ev_span[a][b]);
   if (s->st2) (void)hipStreamDestroy(s->st2);
   if (s->st) (void)hipStreamDestroy(s->st);
@@ -592,7 +593,7 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     return fail(GPIRT_ERR_HIP);
   }
   memset(s->h_look, 0, sizeof(int32_t) * (size_t)(4 + s->cfg.max_ess_rounds + 4));
-  A_(s->d_counters, 6);
+  A_(s->d_counters, 8);   // [6]: checksum of the respondent step's log-likelihood sums (GPIRT_FIXED_ORDER_SUM)
   // nu = L Z with few column tiles (a rank's share of the items, or a handful of items): the
   // longest row panel alone would set the time and most CUs would hold one workgroup or none,
   // so K is cut into slabs that run side by side.  Measured at n = 10 000: 512 columns
@@ -669,7 +670,8 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     bool ok = hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_z, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&s->ev_pref, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&s->ev_pref, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_tail, hipEventDisableTiming) == hipSuccess;
     for (int a = 0; a < 2 && ok; ++a)
       for (int b = 0; b < 2 && ok; ++b) ok = hipEventCreate(&s->ev_span[a][b]) == hipSuccess;
     for (int i = 0; i < max(s->nu_overlap, s->nu_overlap_la) && ok; ++i) {
@@ -860,15 +862,18 @@ static int update_timer(void *ctx, int begin, double flop, hipStream_t stream) {
 // sample_fs.m:2, demo.m:45, without the n x n matrix).  All blocks are independent given the
 // prefix sums: the two factorisations run as batches of the diagonal kernel.  *done = 0 when
 // an input lies outside the nodes' range; the caller then takes the dense route for this sweep.
+static int fstar_status(gpirt_sampler *s);
 static int phase_factor_generator(gpirt_sampler *s, int *done) {
   *done = 0;
   GP_TRY(mark(s, PH_KBUILD));
-  GP_HIP(hipMemsetAsync(s->d_info, 0, 3 * sizeof(int), s->st));
+  // ([2], the status of the low-rank f* step, stays: see fstar_status)
+  GP_HIP(hipMemsetAsync(s->d_info, 0, 2 * sizeof(int), s->st));
   GP_TRY(launch_bary(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->d_nodes, s->d_bw, s->fs_nodes,
                      s->cfg.grid_lo, s->cfg.grid_lo + s->cfg.grid_step * (s->G - 1), s->d_W,
                      (int64_t)s->Np_pad * s->G_pad, s->d_info + 1));
   GP_HIP(hipMemcpyAsync(s->h_look, s->d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, s->st));
   GP_HIP(hipStreamSynchronize(s->st));
+  if (s->fs_lowrank) { s->h_info2 = s->h_look[2]; GP_TRY(fstar_status(s)); }
   if (s->h_look[1]) return GPIRT_OK;
   s->theta_inside = 1;
   GP_TRY(mark(s, PH_POTRF));
@@ -986,6 +991,9 @@ static int nu_panel_hook(void *ctx, int o, int oe) {
     g.M = s->Np_pad - r0; g.N = s->ML; g.K = SUP; g.batch = 1; g.alpha = 1.0; g.beta = sp ? 1.0 : 0.0;
     g.lone = s->nu_lone;
     GP_TRY(launch_gemm(s->st2, false, false, g));
+    // the launch after the factorisation adds to these rows on the main stream: it waits for this event
+    // (recorded ahead of the chunks that this stream receives later, so those still run beside that launch)
+    GP_HIP(hipEventRecord(s->ev_tail, s->st2));
     s->nu_tail_done = sp + 1;
   }
   return GPIRT_OK;
@@ -1080,8 +1088,9 @@ static int phase_factor(gpirt_sampler *s) {
     }
     GP_TRY(mark(s, PH_POTRF));
     // info[0]: pivot of a failed factorisation; [1]: an input outside the range of the f* nodes
-    // ([2], the status of the low-rank f* step's factorisation, is read behind that step)
-    GP_HIP(hipMemsetAsync(s->d_info, 0, 3 * sizeof(int), s->st));
+    // ([2], the status of the low-rank f* step's factorisation, is sticky: only fstar_status clears it,
+    // after it has reported the failure, so a sweep that nobody looked behind cannot lose it)
+    GP_HIP(hipMemsetAsync(s->d_info, 0, 2 * sizeof(int), s->st));
     if (s->fs_lowrank)   // the Lagrange basis at the inputs; it waits in W, which is free until the f* step
       GP_TRY(launch_bary(s->st, s->d_theta, s->Np, s->Np, s->Np_pad, s->P, s->d_nodes, s->d_bw, s->fs_nodes,
                          s->cfg.grid_lo, s->cfg.grid_lo + s->cfg.grid_step * (s->G - 1), s->d_W,
@@ -1093,6 +1102,9 @@ static int phase_factor(gpirt_sampler *s) {
     GP_HIP(hipMemcpyAsync(s->h_look, s->d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, s->st));
     GP_HIP(hipStreamSynchronize(s->st));
     s->theta_inside = !s->h_look[1];
+    // an earlier sweep's low-rank f* step that failed with nobody looking (the grid-mode respondent step
+    // never reads the status inside a sweep) ends the chain here
+    if (s->fs_lowrank) { s->h_info2 = s->h_look[2]; GP_TRY(fstar_status(s)); }
     const int info = s->h_look[0];
     if (!info) {
       GP_TRY(schedule_tune(s));
@@ -1122,6 +1134,8 @@ static int phase_f(gpirt_sampler *s) {
     // the first nu_tail_done panels of L are in these rows of nu already (nu_panel_hook): go on from there
     const int k0 = s->nu_tail_done * SUP;
     g.A += (int64_t)s->Np_pad * k0; g.B += k0; g.K -= k0; g.k_base -= k0; g.beta = 1.0;
+    // those panels' launches ran on the second stream; the last of them wrote the rows this launch adds to
+    GP_HIP(hipStreamWaitEvent(s->st, s->ev_tail, 0));
   }
   // the XCD-aware tile order keeps HBM traffic down when there are many column tiles per row
   // panel; with fewer it is slower than plain longest-first (3.83 vs 3.59 ms at 2048 columns)
@@ -1360,6 +1374,7 @@ static ThetaArgs theta_args(gpirt_sampler *s) {
   a.index_truncate = (s->cfg.flags & GPIRT_INDEX_TRUNCATE) ? 1 : 0;
   a.seed = s->seed; a.sweep = s->sweep; a.remaining = s->d_remaining;
   a.counters = s->d_counters + 4;
+  a.ll_seen = (s->cfg.flags & GPIRT_FIXED_ORDER_SUM) ? s->d_counters + 6 : nullptr;
   a.tab = s->d_tab;
   a.part = s->d_part; a.gidx = s->d_gidx; a.order = s->d_order; a.bstart = s->d_bstart;
   a.ghist = s->d_ghist;
@@ -1406,10 +1421,12 @@ static int phase_theta(gpirt_sampler *s) {
   // GPIRT_FIXED_ORDER_SUM with several ranks: every evaluation is the bucketed one, the ranks exchange
   // the block sums themselves (each rank's blocks in its own slots, zeros in the others': the hook's
   // sum returns every block exactly) and the decision kernel adds all blocks in item order
-  const bool fixed = (s->cfg.flags & GPIRT_FIXED_ORDER_SUM) && s->cfg.world > 1;
+  // (with one rank the flag alone forces the same evaluation and the same order of adding: nothing to exchange)
+  const bool fixed_order = (s->cfg.flags & GPIRT_FIXED_ORDER_SUM) != 0;
+  const bool fixed = fixed_order && s->cfg.world > 1;
   const int64_t slot = (int64_t)THETA_SPEC * s->n;
   auto eval = [&](int initial, bool wide) -> int {
-    const bool bucketed = a.part && (fixed || active * 8 >= s->n);
+    const bool bucketed = a.part && (fixed_order || active * 8 >= s->n);
     a.from_parts = bucketed && (s->cfg.world <= 1 || fixed);   // read by the decision kernel that follows
     if (fixed) {
       if (a.slot0 > 0) GP_HIP(hipMemsetAsync(s->d_part, 0, sizeof(double) * (size_t)(slot * a.slot0), s->st));
@@ -1595,6 +1612,20 @@ int gpirt_sampler_diagnostics(gpirt_sampler *s, gpirt_outputs *o) {
   o->nu_rows_beside_factor = s->gen_now ? 0 : s->nu_rows_done;
   o->factor_lookahead = s->gen_now ? 0 : s->la_now;
   o->nu_tail_panels = s->gen_now ? 0 : s->nu_tail_done;
+  return GPIRT_OK;
+}
+
+int gpirt_sampler_ll_checksum(gpirt_sampler *s, uint64_t *out) {
+  if (!s || !out) { set_error("NULL argument"); return GPIRT_ERR_BAD_ARG; }
+  if (!(s->cfg.flags & GPIRT_FIXED_ORDER_SUM)) {
+    set_error("gpirt_sampler_ll_checksum: the sampler was not created with GPIRT_FIXED_ORDER_SUM");
+    return GPIRT_ERR_BAD_ARG;
+  }
+  GP_HIP(hipSetDevice(s->device));
+  GP_HIP(hipStreamSynchronize(s->st));
+  unsigned long long v = 0;
+  GP_HIP(hipMemcpy(&v, s->d_counters + 6, sizeof v, hipMemcpyDeviceToHost));
+  *out = (uint64_t)v;
   return GPIRT_OK;
 }
 

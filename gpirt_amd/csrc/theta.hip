@@ -357,16 +357,17 @@ int launch_theta_eval(hipStream_t st, const ThetaArgs &a, int initial, bool wide
 // q0, q0+1, ... in order and stops at the first accepted one.  A respondent that is still
 // active then gets its next THETA_SPEC proposals, each drawn from the bracket that the
 // rejection of the one before would leave (:92-100).
-__global__ void theta_decide_kernel(ThetaArgs a, int q0, int round) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
+__device__ inline void theta_decide_one(const ThetaArgs &a, int q0, int round, int i, unsigned long long &seen) {
   const int H = a.H, n = a.n;
   const int64_t V = (int64_t)THETA_SPEC * n;
   auto value = [&](int k) -> double {
     const int64_t v = (int64_t)k * n + i;
-    if (!a.from_parts) return a.buf[v];
-    double ll = 0.0;         // bucketed evaluation: the chunk partials, summed in fixed order
-    for (int ch = 0; ch < a.nslots; ++ch) ll += a.part[V * ch + v];
+    double ll = 0.0;
+    if (!a.from_parts) ll = a.buf[v];
+    else                     // bucketed evaluation: the chunk partials, summed in fixed order
+      for (int ch = 0; ch < a.nslots; ++ch) ll += a.part[V * ch + v];
+    // every sum a decision reads, by its bits and its place (a.ll_seen only)
+    seen += (unsigned long long)__double_as_longlong(ll) * (unsigned long long)(2 * v + 1);
     return ll;
   };
   auto finish = [&](int q, bool capped) {
@@ -432,6 +433,17 @@ __global__ void theta_decide_kernel(ThetaArgs a, int q0, int round) {
     for (int k = cnt; k < THETA_SPEC; ++k) a.gidx[(int64_t)k * n + i] = -1;
   a.done[i] = cnt;
   atomicAdd(&a.remaining[round], 1);
+}
+
+__global__ void theta_decide_kernel(ThetaArgs a, int q0, int round) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long seen = 0;
+  if (i < a.n) theta_decide_one(a, q0, round, i, seen);
+  if (a.ll_seen) {           // one wrapping sum per wave, then one atomic
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) seen += __shfl_xor(seen, off, 64);
+    if ((threadIdx.x & 63) == 0 && seen) atomicAdd(a.ll_seen, seen);
+  }
 }
 
 int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int q0, int round) {

@@ -129,6 +129,13 @@ class Sampler:
         check(lib().gpirt_sampler_diagnostics(self._h, C.byref(o)))
         return bool(o.factor_lookahead)
 
+    def ll_checksum(self):
+        """GPIRT_FIXED_ORDER_SUM only: 64-bit checksum of every log-likelihood sum that the
+        respondent step's decisions have read so far (equal for chains whose sums agree bit for bit)."""
+        v = C.c_uint64()
+        check(lib().gpirt_sampler_ll_checksum(self._h, C.byref(v)))
+        return int(v.value)
+
     def accumulate(self, quadratic=False, skip_theta=False):
         """Add the current state to the device-side running sums of the posterior summaries
         (`skip_theta`: leave theta out of this draw's sums)."""

@@ -261,6 +261,12 @@ int gpirt_sampler_phase_times(gpirt_sampler *s, double *ms, int64_t *count);
 int gpirt_sampler_update_times(gpirt_sampler *s, double *ms, int64_t *launches, double *flop);
 /* Diagnostics so far: fills the counters of `out` (buffers untouched). */
 int gpirt_sampler_diagnostics(gpirt_sampler *s, gpirt_outputs *out);
+/* GPIRT_FIXED_ORDER_SUM only: a 64-bit checksum of every per-respondent log-likelihood sum that
+ * the respondent step's decisions have read since creation -- the wrapping sum of (bit pattern of
+ * the sum) x (2 x entry + 1) over all of them.  Chains whose sums agree bit for bit, for whatever
+ * number of ranks, return the same word; a single differing bit changes it.  No counterpart in the
+ * reference (single process, nothing to compare). */
+int gpirt_sampler_ll_checksum(gpirt_sampler *s, uint64_t *out);
 /* ---- posterior summaries from running sums on the device ---------------------------
  * What the reference's R post-processing derives from the kept draws
  * (gpirt-sythetic.R:111-133,151-214,231-251; getprob_gpirt.R:1-20), accumulated on the
@@ -329,8 +335,10 @@ int gpirt_k_build(const double *x, int32_t n, double ls, double sf, double jitte
  * chol(K) idiom generate_data.R:56).  L[n,n], strict upper triangle zeroed.
  * Returns GPIRT_ERR_NOT_PD when a pivot is not positive. */
 int gpirt_potrf(const double *S, int32_t n, double *L);
-/* gpirt_potrf for callers that cannot allocate device memory (code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+/* gpirt_potrf for callers that cannot allocate device memory (tight serving loops, harnesses
+ * that forbid hipMalloc).  It allocates nothing, but it does copy the status word to the host and
+ * waits for the stream before it returns, so it is NOT for a stream under HIP graph capture.
+ * No counterpart in the reference.
  * DEVICE pointers in and out: d_S [n,n] column-major with leading dimension lds (both
  * triangles are read as gpirt_potrf reads them), d_L [n,n] with leading dimension ldl receives
  * the lower factor with a zero strict upper triangle (d_L may be d_S).  `stream` is a

@@ -46,7 +46,10 @@ const char *gpirt_comm_last_error(void);
 int gpirt_comm_unique_id(void *id);
 /* All ranks, each with its own device current: join the communicator. */
 int gpirt_comm_create(const void *id, int32_t rank, int32_t world, gpirt_comm **out);
-/* Write rank, world, the hook below, its user pointer and GPIRT_ALLREDUCE_ON_STREAM into cfg. */
+/* Write rank, world, the hook below, its user pointer and GPIRT_ALLREDUCE_ON_STREAM into cfg, and
+ * allocate the all-gather's staging for the largest vector a sweep of THIS configuration exchanges
+ * (call it with n, m, C, n_grid, theta_mode and flags final), so that no exchange inside a sweep
+ * allocates or drains the stream. */
 int gpirt_comm_bind(gpirt_comm *c, gpirt_config *cfg);
 /* The HIP stream (hipStream_t) the collectives are enqueued on: gpirt_sampler_stream(s). */
 int gpirt_comm_set_stream(gpirt_comm *c, void *stream);
@@ -55,6 +58,10 @@ int gpirt_comm_set_stream(gpirt_comm *c, void *stream);
 int gpirt_comm_allreduce(double *d_buf, int64_t count, void *comm);
 /* Number of collectives enqueued so far. */
 int64_t gpirt_comm_calls(const gpirt_comm *c);
+/* Ranks in the communicator as RCCL itself reports them (ncclCommCount); 0 on failure. */
+int gpirt_comm_world(const gpirt_comm *c);
+/* Doubles per rank the all-gather's staging holds now. */
+int64_t gpirt_comm_capacity(const gpirt_comm *c);
 void gpirt_comm_destroy(gpirt_comm *c);
 
 #ifdef __cplusplus

@@ -90,6 +90,75 @@ def test_two_ranks_on_one_gpu_match_unsharded_device_chain(tmp_path, grid, torch
         assert np.abs(p["beta"] - full["beta"][:, j0:j1]).max() < 1e-9
 
 
+def _taps_worker(rank, world, port, out_dir, kernel):
+    """One of two ranks on the TAPS cut with the arguments of TAPS/gpirt_TAPS.R:17-36
+    (`constant_IRF = 1`: 2460 stacked inputs per item), three of the six questions each."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from gpirt_amd import _abi, _lib
+    _lib.check(_lib.lib().gpirt_set_device(0))
+    import torch.distributed as dist
+    from gpirt_amd.builders import standardised_row_scores
+    from gpirt_amd.dist import host_staged_allreduce, item_range
+    from gpirt_amd.sampler import Sampler
+    from test_gpu_config_d import taps, taps_arguments
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    y = np.ascontiguousarray(taps()[:60])
+    n, m, H = y.shape
+    bps, tps = taps_arguments(n, m)
+    j0, j1 = item_range(m, rank, world)
+    hook = host_staged_allreduce()
+    cb = _abi.ALLREDUCE_FN(lambda ptr, count, user: hook(ptr, count))
+    cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=1, theta_os=1.0, theta_ls=12.0, kernel=kernel,
+                              constant_irf=1, item_begin=j0, item_end=j1, rank=rank, world=world)
+    cfg.allreduce = cb
+    with Sampler(cfg, y, theta_init=standardised_row_scores(y), beta_prior_sds=bps, theta_prior_sds=tps) as s:
+        s.sweep(3)
+        st, dg = s.state(), s.diagnostics()
+    np.savez(os.path.join(out_dir, "taps_k%d_r%d.npz" % (kernel, rank)), j0=j0, j1=j1,
+             theta_rounds=dg["ess_theta_rounds"], **st)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kernel", [0, 1], ids=["RBF", "Matern"])
+def test_taps_panel_sharded_over_two_ranks_matches_the_unsharded_device_chain(tmp_path, kernel):
+    """Dynamic GPIRT on the TAPS panel with the items sharded (TAPS/gpirt_TAPS.R:30-36,
+    TAPS/onerun:21-25: `constant_IRF = 1`, both temporal kernels): two ranks sharing the GPU, three
+    questions each, against the unsharded device chain, which test_taps_cut_matches_oracle ties to
+    the oracle sweep by sweep.  theta is the same chain to rounding (the ranks' partial sums are
+    re-associated), each rank's f / f* / beta / thresholds are its slice of the unsharded ones."""
+    import torch.multiprocessing as mp
+    from gpirt_amd import _abi
+    from gpirt_amd.builders import standardised_row_scores
+    from gpirt_amd.sampler import Sampler
+    from test_gpu_config_d import taps, taps_arguments
+
+    mp.spawn(_taps_worker, args=(2, _free_port(), str(tmp_path), kernel), nprocs=2, join=True)
+    y = np.ascontiguousarray(taps()[:60])
+    n, m, H = y.shape
+    bps, tps = taps_arguments(n, m)
+    cfg = _abi.default_config(n=n, m=m, H=H, C=5, seed=1, theta_os=1.0, theta_ls=12.0, kernel=kernel,
+                              constant_irf=1)
+    with Sampler(cfg, y, theta_init=standardised_row_scores(y), beta_prior_sds=bps, theta_prior_sds=tps) as ref:
+        ref.sweep(3)
+        full, dg = ref.state(), ref.diagnostics()
+    for r in range(2):
+        p = np.load(os.path.join(str(tmp_path), "taps_k%d_r%d.npz" % (kernel, r)))
+        j0, j1 = int(p["j0"]), int(p["j1"])
+        assert (j0, j1) == (3 * r, 3 * r + 3)
+        assert int(p["theta_rounds"]) == dg["ess_theta_rounds"]
+        assert np.abs(p["theta"] - full["theta"]).max() < 1e-9
+        assert np.abs(p["beta"] - full["beta"][:, j0:j1]).max() < 1e-9
+        fin = np.isfinite(full["threshold"][j0:j1])
+        assert np.abs(p["threshold"][fin] - full["threshold"][j0:j1][fin]).max() < 1e-9
+        assert np.abs(p["f"] - full["f"][:, j0:j1]).max() < 1e-5
+        assert np.abs(p["fstar"] - full["fstar"][:, j0:j1]).max() < 1e-5
+
+
 def _nccl_worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -273,8 +342,10 @@ def _fixed_worker(rank, world, port, out_dir):
     with Sampler(cfg, d["y"], theta_init=d["theta"]) as s:
         s.sweep(3)
         st = s.state(fstar=False)
+        seen = s.ll_checksum()
     np.savez(os.path.join(out_dir, "fixed_w%d_r%d.npz" % (world, rank)), j0=cfg.item_begin,
-             j1=cfg.item_end if world > 1 else m, **{k: v for k, v in st.items() if v is not None})
+             j1=cfg.item_end if world > 1 else m, ll_checksum=np.uint64(seen),
+             **{k: v for k, v in st.items() if v is not None})
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -283,7 +354,8 @@ def _fixed_worker(rank, world, port, out_dir):
 def test_fixed_order_sum_gives_the_same_bits_for_one_two_and_four_ranks(tmp_path):
     """GPIRT_FIXED_ORDER_SUM: the respondent step adds the sums of fixed 512-item blocks in item order
     whatever the sharding, so theta -- and with it every rank's share of f and beta -- is the
-    unsharded chain's bit for bit (1536 respondents, 2048 items: 4 blocks; 1, 2 and 4 ranks)."""
+    unsharded chain's bit for bit (1536 respondents, 2048 items: 4 blocks; 1, 2 and 4 ranks) -- by
+    construction: the log-likelihood sums behind the decisions are equal bit for bit too."""
     import torch.multiprocessing as mp
     out = str(tmp_path)
     for world in (1, 2, 4):
@@ -296,6 +368,10 @@ def test_fixed_order_sum_gives_the_same_bits_for_one_two_and_four_ranks(tmp_path
             assert np.array_equal(p["theta"], full["theta"]), (world, r)
             assert np.array_equal(p["f"], full["f"][:, j0:j1]), (world, r)
             assert np.array_equal(p["beta"], full["beta"][:, j0:j1]), (world, r)
+            # the sums themselves, not only the decisions they led to: the checksum covers every
+            # log-likelihood sum any decision read, late rounds with few active respondents included
+            # (one rank takes the bucketed, block-wise evaluation there too)
+            assert int(p["ll_checksum"]) == int(full["ll_checksum"]) != 0, (world, r)
 
 
 def test_fixed_order_sum_refuses_ranges_off_the_block_grid():

@@ -15,7 +15,7 @@ seeds and the spread of each metric over seeds is the yardstick the CPU-vs-devic
 held to (`tolerance`).
 
 Run as a script on a GPU box to regenerate the committed table:
-    python tests/tier2_parity.py profiles/r02_tier2_parity.json
+    python tests/tier2_parity.py profiles/r03_tier2_parity.json
 TEST INFRASTRUCTURE (it drives the CPU oracle): used by tests/test_gpu_tier2.py only.
 """
 import json
@@ -111,6 +111,62 @@ def run_fixture(stem, C):
                                     for k, v in dev["diagnostics"].items()})
 
 
+def run_mid_rung(n=2500, m=1024, C=5, burn=100, sample=100, seed=1):
+    """A rung between the reference's n = 100 data files and the scale-out size, where the device takes
+    its large-size code paths (a workgroup per unit in the slice kernels, the tabulated and bucketed
+    respondent step, several super-panels in the factorisation): synthetic data by the recipe of
+    generate_data.R:36-48,92-119, `theta_init = theta + 0.05 N(0,1)` (gpirt-sythetic.R:86), burn + sample
+    sweeps on the device and on the CPU oracle with the same streams, compared sweep by sweep."""
+    from gpirt_amd import _abi
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synth import generate
+    from oracle import oracle
+    d = generate(n, m, C, seed=seed)
+    init = d["theta"] + 0.05 * np.random.default_rng(seed).normal(size=d["theta"].shape)
+    cfg = _abi.default_config(n=n, m=m, H=1, C=C, seed=seed)
+    g, c = Sampler(cfg, d["y"], theta_init=init), oracle.Sampler(cfg, d["y"], theta_init=init)
+    sum_g, sum_c = np.zeros(n), np.zeros(n)
+    first_split, worst = None, 0.0
+    t_dev = t_cpu = 0.0
+    for it in range(burn + sample):
+        t0 = time.perf_counter(); g.sweep(1); t_dev += time.perf_counter() - t0
+        t0 = time.perf_counter(); c.sweep(1); t_cpu += time.perf_counter() - t0
+        tg, tc = g.state(f=False, fstar=False)["theta"][:, 0], c.state()["theta"][:, 0]
+        diff = float(np.abs(tg - tc).max())
+        if first_split is None:
+            worst = max(worst, diff)
+            if diff > 1e-6:
+                first_split = it + 1
+        if it >= burn:
+            sum_g += tg
+            sum_c += tc
+    dg, dc = g.diagnostics(), c.diagnostics()
+    g.close(); c.close()
+    th_g, th_c = sum_g / sample, sum_c / sample
+    return dict(rung="synthetic n=%d m=%d C=%d H=1" % (n, m, C), sweeps=dict(burn=burn, sample=sample),
+                cor_theta_hat_cpu_vs_device=float(np.corrcoef(th_g, th_c)[0, 1]),
+                cor_theta_hat_device_vs_generating=float(np.corrcoef(th_g, d["theta"][:, 0])[0, 1]),
+                cor_theta_hat_cpu_vs_generating=float(np.corrcoef(th_c, d["theta"][:, 0])[0, 1]),
+                max_abs_diff_theta_hat=float(np.abs(th_g - th_c).max()),
+                first_sweep_with_theta_apart_by_1e6=first_split,
+                max_abs_theta_diff_while_together=worst,
+                device_diagnostics={k: int(v) for k, v in dg.items()},
+                cpu_diagnostics={k: int(v) for k, v in dc.items()},
+                diagnostics_equal=dg == dc,
+                seconds=dict(device=round(t_dev, 2), cpu_oracle=round(t_cpu, 2)))
+
+
+def check_mid_rung(row):
+    bad = []
+    if not row["cor_theta_hat_cpu_vs_device"] >= 0.99:
+        bad.append("%s: cor(theta_hat cpu, device) = %.4f < 0.99" % (row["rung"], row["cor_theta_hat_cpu_vs_device"]))
+    if row["first_sweep_with_theta_apart_by_1e6"] is None and not row["diagnostics_equal"]:
+        bad.append("%s: the chains stayed together but their evaluation counters differ" % row["rung"])
+    if row["device_diagnostics"]["ess_capped"] != 0:
+        bad.append("%s: capped slice updates on the device" % row["rung"])
+    return bad
+
+
 def check(row):
     """The assertions of the parity bar; returns the list of violations."""
     bad = []
@@ -127,10 +183,11 @@ def check(row):
 
 if __name__ == "__main__":
     rows = [run_fixture(stem, C) for stem, C in FIXTURES]
+    mid = run_mid_rung()
     table = dict(settings="gpirt-sythetic.R:60-94: 500 + 500 sweeps, THIN 4, theta_init = theta + 0.05 N(0,1), "
                           "theta_ls = H/2, RBF, thresholds sampled, constant_IRF = 0",
                  metrics=list(METRICS), tolerance_rule="max(%g x sd over %d device seeds, floor)" % (K_SIGMA, N_SEEDS + 1),
-                 rows=rows, violations=[b for r in rows for b in check(r)])
+                 rows=rows, mid_rung=mid, violations=[b for r in rows for b in check(r)] + check_mid_rung(mid))
     text = json.dumps(table, indent=1)
     if len(sys.argv) > 1:
         with open(sys.argv[1], "w") as fh:
@@ -141,5 +198,7 @@ if __name__ == "__main__":
         for k in METRICS:
             print("   %-20s cpu %9.4f  device %9.4f  |diff| %.4f  tol %.4f" %
                   (k, r["cpu_oracle"][k], r["device"][k], r["abs_diff"][k], r["tolerance"][k]))
+    print(mid["rung"], "cor(cpu,device) %.5f" % mid["cor_theta_hat_cpu_vs_device"], "first split at sweep",
+          mid["first_sweep_with_theta_apart_by_1e6"], "counters equal", mid["diagnostics_equal"], mid["seconds"])
     print("violations:", table["violations"])
     sys.exit(1 if table["violations"] else 0)
