@@ -162,9 +162,13 @@ __host__ __device__ inline int64_t inv_group_elems(int n_pad) { return (int64_t)
 __host__ __device__ inline int64_t inv_block_offset(int kb) {   // 128-block kb inside its group's inverse image
   return (int64_t)(kb / 4) * SUP * SUP + (int64_t)(kb % 4) * TILE * (SUP + 1);
 }
-// scratch the factorisation needs: 256*256 doubles per super-block and group
+// scratch the factorisation needs: 256*256 doubles per super-block and group for the inverted super-blocks,
+// and two raw copies of a super-panel's rows inside the diagonal super-block (3 TILE x TILE each) per group
+// for the steps inside a super-panel (the two uses never overlap in time)
+constexpr int64_t POTRF_RAW_ELEMS = 2 * 3 * (int64_t)TILE * TILE;
 inline int64_t potrf_work_elems(int n_pad, int batch) {
-  return (int64_t)inv_nsup(n_pad) * 256 * 256 * batch;
+  const int64_t inv = (int64_t)inv_nsup(n_pad) * 256 * 256;
+  return (inv > POTRF_RAW_ELEMS ? inv : POTRF_RAW_ELEMS) * batch;
 }
 // In-place lower Cholesky of `batch` padded matrices + the inverted diagonal super-blocks
 // (inv must be zero-initialised once); *d_info (device int) is set non-zero when a pivot is

@@ -1001,6 +1001,10 @@ int launch_potrf_diag(hipStream_t st, double *S, int n_pad, int kb, int batch, d
                       int *d_info, bool offdiag);
 int launch_trsm_panel(hipStream_t st, double *S, int n_pad, int kb, int batch, const double *inv_diag);
 int launch_block_inverses(hipStream_t st, const double *S, int n_pad, int batch, double *inv_diag);
+int launch_potrf_rawcopy(hipStream_t st, const double *S, int n_pad, int kb, int oe, int batch, double *raw);
+int launch_potrf_inpanel(hipStream_t st, double *S, int n_pad, int kb, int o, int oe, int batch,
+                         const double *inv_diag, double *raw);
+int launch_potrf_tall(hipStream_t st, double *S, int n_pad, int o, int oe, int batch, const double *inv_diag);
 
 // Off-diagonal blocks of the inverted diagonal super-blocks by block substitution: for a
 // lower-triangular [[A,0],[B,C]] the inverse is [[A^-1,0],[-C^-1 B A^-1, C^-1]].
@@ -1096,12 +1100,29 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
     return u;
   };
   const bool ahead = hook && hook->side && hook->ev && batch == 1;
+  // The steps of a super-panel with the diagonal super-block first (potrf_diag.hip): per 128 columns the
+  // diagonal kernel and ONE launch for panel solve + update inside the super-block, then one launch for all
+  // rows below.  Measured at n = 10 000: the steps inside the super-block take 14.5 us against 15 + 19, but the launch
+  // for the rows below takes 87 us whatever their number (2112 dependent MFMAs per wave), which is more than those rows
+  // cost in the step-by-step form: factorisation alone 10.9 against 10.2 ms.  So the step-by-step form over all rows
+  // (three launches per step) stays the default; GPIRT_POTRF_STEPWISE=0 selects the form above.
+  static const bool stepwise = !(getenv("GPIRT_POTRF_STEPWISE") && atoi(getenv("GPIRT_POTRF_STEPWISE")) == 0);
+  const bool block_first = subst && !stepwise && work != nullptr;
   for (int o = 0; o < nb; o += 4) {
     const int oe = min(o + 4, nb), sp = o / 4;
-    for (int k = o; k < oe; ++k) {
-      GP_TRY(launch_potrf_diag(st, S, n_pad, k, batch, inv, nb, d_info, !subst));
-      if (k + 1 < nb) GP_TRY(panel_solve(k));
-      GP_TRY(update_rect(k, k + 1, oe));
+    if (block_first) {
+      GP_TRY(launch_potrf_rawcopy(st, S, n_pad, o, oe, batch, work));
+      for (int k = o; k < oe; ++k) {
+        GP_TRY(launch_potrf_diag(st, S, n_pad, k, batch, inv, nb, d_info, false));
+        GP_TRY(launch_potrf_inpanel(st, S, n_pad, k, o, oe, batch, inv, work));
+      }
+      GP_TRY(launch_potrf_tall(st, S, n_pad, o, oe, batch, inv));
+    } else {
+      for (int k = o; k < oe; ++k) {
+        GP_TRY(launch_potrf_diag(st, S, n_pad, k, batch, inv, nb, d_info, !subst));
+        if (k + 1 < nb) GP_TRY(panel_solve(k));
+        GP_TRY(update_rect(k, k + 1, oe));
+      }
     }
     if (oe < nb && !ahead) {
       GemmArgs u = trailing(o, oe, oe, 0);

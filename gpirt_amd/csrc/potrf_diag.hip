@@ -441,6 +441,330 @@ int launch_trsm_panel(hipStream_t st, double *S, int n_pad, int kb, int batch, c
   return GPIRT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The steps of a 512-column super-panel with the diagonal super-block FIRST.  The chain of small
+// kernels that the factorisation's critical path consists of (diagonal block, panel solve, update
+// of the rest of the super-panel, once per 128 columns) costs what its launches' first loads and
+// stores cost, whatever the number of rows -- so the rows BELOW the diagonal super-block leave the
+// chain: per 128-column step the chain only touches the at most 384 rows of the super-block
+// (potrf_inpanel_kernel: panel solve and update in ONE launch), and all rows below take the whole
+// super-panel in one launch afterwards (potrf_tall_kernel: X = A L_ss^-T by block substitution
+// over the four block columns, a row block's chain kept in registers).
+//
+// Both kernels solve 16 rows per wave by the substitution of trsm_panel_kernel, from the same
+// ten 32 x 32 blocks of the diagonal block (here the six blocks below the diagonal are staged
+// NEGATED, which takes the sign flips out of the loops).
+// ---------------------------------------------------------------------------------------------
+struct DiagBlocks { double2 st[TRSM_BLOCKS][2]; };
+
+// raw buffer access: a wave-uniform base (scalar registers), one fixed 32-bit offset per lane and a
+// scalar offset per access -- no 64-bit address per lane and access
+typedef __amdgpu_buffer_rsrc_t prsrc_t;
+__device__ __forceinline__ prsrc_t panel_rsrc(const void *p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ double pbuf_ld(prsrc_t r, uint32_t lane_off, uint32_t wave_off) {
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, wave_off, 0);
+  double d;
+  __builtin_memcpy(&d, &v, 8);
+  return d;
+}
+__device__ __forceinline__ void pbuf_st(prsrc_t r, uint32_t lane_off, uint32_t wave_off, double d) {
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  v2u v;
+  __builtin_memcpy(&v, &d, 8);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, lane_off, wave_off, 0);
+}
+__device__ __forceinline__ double2 pbuf_ld2(prsrc_t r, uint32_t lane_off, uint32_t wave_off) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, wave_off, 0);
+  double2 d;
+  __builtin_memcpy(&d, &v, 16);
+  return d;
+}
+
+// thread t carries rows (2 (t & 15), +1) of columns (t >> 4) and (t >> 4) + 16 of each block
+__device__ __forceinline__ void diag_blocks_load(DiagBlocks &d, const double *__restrict__ Lkk, int64_t n_pad,
+                                                 const double *__restrict__ Inv, int tid) {
+  const int si = (tid & 15) << 1, sk = tid >> 4;
+#pragma unroll
+  for (int p = 1; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < p; ++q)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        d.st[trsm_slot(p, q)][h] = *reinterpret_cast<const double2 *>(Lkk + 32 * p + si + n_pad * (32 * q + sk + 16 * h));
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      d.st[6 + p][h] = *reinterpret_cast<const double2 *>(Inv + 32 * p + si + (int64_t)SUP * (32 * p + sk + 16 * h));
+}
+
+__device__ __forceinline__ void diag_blocks_store(const DiagBlocks &d, double (*blk)[SB * SB], int tid) {
+  const int si = (tid & 15) << 1, sk = tid >> 4;
+#pragma unroll
+  for (int b = 0; b < TRSM_BLOCKS; ++b)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const double sg = b < 6 ? -1.0 : 1.0;
+      *reinterpret_cast<double2 *>(&blk[b][trsm_at(si, sk + 16 * h)]) = make_double2(sg * d.st[b][h].x, sg * d.st[b][h].y);
+    }
+}
+
+// xt (16 rows of a panel, transposed in accumulator layout: xt[t][r] of lane (lr, lk) is the row's
+// entry in column 16 t + lk + 4 r) <- xt L_kk^-T
+__device__ __forceinline__ void solve16(v4d (&xt)[8], const double (*blk)[SB * SB], int lr, int lk) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    v4d w[2] = {xt[2 * p], xt[2 * p + 1]};
+#pragma unroll
+    for (int q = 0; q < p; ++q) {
+      const double *Lpq = blk[trsm_slot(p, q)];      // negated
+      // (the fences keep the reads of one block together: unfenced, the compiler lifts the reads of all
+      // ten blocks to the top, 300 registers' worth)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const double x = xt[2 * q + (ks >> 2)][ks & 3];
+        const int k = 4 * ks + lk;
+        w[0] = mfma4(Lpq[trsm_at(lr, k)], x, w[0]);
+        w[1] = mfma4(Lpq[trsm_at(16 + lr, k)], x, w[1]);
+      }
+    }
+    const double *Xpp = blk[6 + p];
+    v4d o0 = {0.0, 0.0, 0.0, 0.0}, o1 = {0.0, 0.0, 0.0, 0.0};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {      // X_pp is lower-triangular: its upper 16 rows stop at column 16
+      const double x = w[ks >> 2][ks & 3];
+      const int k = 4 * ks + lk;
+      if (ks < 4) o0 = mfma4(Xpp[trsm_at(lr, k)], x, o0);
+      o1 = mfma4(Xpp[trsm_at(16 + lr, k)], x, o1);
+    }
+    xt[2 * p] = o0;
+    xt[2 * p + 1] = o1;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Copy of the raw rows [(kb+1) TILE, oe TILE) of block column kb, [RAW_LD x TILE] per group: what
+// potrf_inpanel_kernel reads while its own waves overwrite those rows in place.
+constexpr int RAW_LD = 3 * TILE;
+constexpr int64_t RAW_ELEMS = (int64_t)RAW_LD * TILE;
+static_assert(2 * RAW_ELEMS == POTRF_RAW_ELEMS, "raw panel buffers");
+
+__global__ __launch_bounds__(256) void potrf_rawcopy_kernel(const double *__restrict__ S, int n_pad, int kb, int rows,
+                                                            double *__restrict__ raw, int64_t raw_stride) {
+  const int z = blockIdx.y, c = blockIdx.x;
+  const double *src = S + (int64_t)n_pad * n_pad * z + (int64_t)(kb + 1) * TILE + (int64_t)n_pad * (kb * TILE + c);
+  double *dst = raw + raw_stride * z + (int64_t)RAW_LD * c;
+  const int r = 2 * threadIdx.x;
+  if (r < rows) *reinterpret_cast<double2 *>(dst + r) = *reinterpret_cast<const double2 *>(src + r);
+}
+
+// One 128-column step inside the diagonal super-block [o, oe): block column kb is factored; the
+// rows [(kb+1) TILE, oe TILE) of it are solved, L_ik = A_ik L_kk^-T, and the block columns kb+1..oe-1
+// of those rows take the panel's update, A_ij -= L_ik L_jk^T (lower 16 x 16 tiles), in ONE launch.
+// A wave owns one 16 x 16 tile (gi, gj) of the update and solves the two 16-row groups it needs
+// itself -- from the raw copy of the panel (raw_in), because the waves of the diagonal tiles write
+// the solved rows over the panel in place while other waves still read the raw rows.  The solved
+// groups are, as they stand in the accumulators, the two operands of the tile's product.  The tiles
+// of block column kb+1 below its diagonal block are the next step's raw panel: they are stored a
+// second time into raw_out.
+__global__ __launch_bounds__(256) void potrf_inpanel_kernel(double *__restrict__ S, int n_pad, int kb, int oe,
+                                                            const double *__restrict__ inv_diag,
+                                                            const double *__restrict__ raw_in,
+                                                            double *__restrict__ raw_out, int64_t raw_stride) {
+  __shared__ __attribute__((aligned(16))) double blk[TRSM_BLOCKS][SB * SB];
+  __builtin_amdgcn_s_setprio(3);
+  const int z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  double *Sz = S + (int64_t)n_pad * n_pad * z;
+  const double *Lkk = Sz + (int64_t)kb * TILE * (n_pad + 1);
+  const double *Inv = inv_diag + inv_group_elems(n_pad) * z + inv_block_offset(kb);
+  const double *Rin = raw_in + raw_stride * z;
+  double *Rout = raw_out + raw_stride * z;
+  const int G = (oe - kb - 1) * (TILE / 16), ntiles = G * (G + 1) / 2;
+  const int T = blockIdx.x * 4 + wave;
+  const bool live = T < ntiles;                       // uniform over the wave
+  int gi = 0, gj = 0;
+  if (live) {
+    gi = (int)((sqrtf(8.0f * (float)T + 1.0f) - 1.0f) * 0.5f);
+    while ((gi + 1) * (gi + 2) / 2 <= T) ++gi;
+    while (gi * (gi + 1) / 2 > T) --gi;
+    gj = T - gi * (gi + 1) / 2;
+  }
+  DiagBlocks d;
+  diag_blocks_load(d, Lkk, n_pad, Inv, tid);
+  v4d xi[8], xj[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xi[t][r] = Rin[(16 * gi + lr) + (int64_t)RAW_LD * (16 * t + lk + 4 * r)];
+      xj[t][r] = Rin[(16 * gj + lr) + (int64_t)RAW_LD * (16 * t + lk + 4 * r)];
+    }
+  diag_blocks_store(d, blk, tid);
+  __syncthreads();
+  if (!live) return;
+  const int rows0 = (kb + 1) * TILE;
+  // the tile of the update comes in early: its latency hides under the solves
+  double *Ct = Sz + (rows0 + 16 * gi + lr) + (int64_t)n_pad * (rows0 + 16 * gj + lk);
+  v4d c;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = Ct[(int64_t)n_pad * (4 * r)];
+  solve16(xi, blk, lr, lk);
+  if (gi != gj) {
+    solve16(xj, blk, lr, lk);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) xj[t] = xi[t];
+    // this wave owns the row group: the solved rows go over the panel
+    double *P = Sz + (rows0 + 16 * gi + lr) + (int64_t)n_pad * (kb * TILE + lk);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[(int64_t)n_pad * (16 * t + 4 * r)] = xi[t][r];
+  }
+  // acc[r] of lane (lr, lk) = sum_c X_j[4 r + lk][c] X_i[lr][c]; two chains of 16
+  v4d a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int t = 0; t < 8; t += 2)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      a0 = mfma4(xj[t][r], xi[t][r], a0);
+      a1 = mfma4(xj[t + 1][r], xi[t + 1][r], a1);
+    }
+  const bool next_panel = gj < TILE / 16 && gi >= TILE / 16;    // block column kb+1, below its diagonal block
+  double *Rt = Rout + (16 * gi - TILE + lr) + (int64_t)RAW_LD * (16 * gj + lk);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double v = c[r] - (a0[r] + a1[r]);
+    Ct[(int64_t)n_pad * (4 * r)] = v;
+    if (next_panel) Rt[(int64_t)RAW_LD * (4 * r)] = v;
+  }
+}
+
+// All rows below the diagonal super-block [o, o + nc) take the whole super-panel in one launch:
+// X = A L_ss^-T by block substitution over the nc block columns,
+//   X_c = (A_c - sum_{c' < c} X_c' L_cc'^T) L_cc^-T.
+// A workgroup owns 64 rows, a wave 16 of them, whose chain stays in registers from the first block
+// column to the last (the solved blocks are the second operands of the later blocks' products as
+// they stand in the accumulators).  The factors are shared by every workgroup and come through
+// LDS: L_cc' NEGATED, in pieces of 32 columns (the next piece's loads are in flight during the
+// current piece's 64 MFMAs per wave), and the ten 32 x 32 blocks of L_cc for the substitution.
+constexpr int TALL_PIECE = 32;
+__device__ __forceinline__ int piece_at(int i, int k) { return k * TILE + (i ^ ((k & 1) << 4)); }
+
+template <int NC>
+__global__ __launch_bounds__(256) void potrf_tall_kernel(double *__restrict__ S, int n_pad, int o,
+                                                         const double *__restrict__ inv_diag) {
+  __shared__ __attribute__((aligned(16))) double blk[TRSM_BLOCKS][SB * SB];
+  __shared__ __attribute__((aligned(16))) double piece[TILE * TALL_PIECE];
+  __builtin_amdgcn_s_setprio(2);
+  const int z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  double *Sz = S + (int64_t)n_pad * n_pad * z;
+  const int row0 = (o + NC) * TILE + 64 * blockIdx.x + 16 * wave;
+  // staging of a piece: thread t carries rows (2 (t & 63), +1) of columns (t >> 6) + 4 h, h = 0..7
+  const int pi = (tid & 63) << 1, pk = tid >> 6;
+  const uint32_t colb = (uint32_t)n_pad * 8u;            // bytes per column: every offset below stays under 128 columns
+  const uint32_t piece_off = (uint32_t)pi * 8u + colb * (uint32_t)pk, row_off = (uint32_t)lr * 8u + colb * (uint32_t)lk;
+  auto piece_load = [&](double2 (&pr)[8], int c, int cp, int q) {
+    const prsrc_t rs = panel_rsrc(Sz + (int64_t)(o + c) * TILE + (int64_t)n_pad * ((o + cp) * TILE + TALL_PIECE * q));
+#pragma unroll
+    for (int h = 0; h < 8; ++h) pr[h] = pbuf_ld2(rs, piece_off, colb * (uint32_t)(4 * h));
+  };
+  auto piece_store = [&](const double2 (&pr)[8]) {
+#pragma unroll
+    for (int h = 0; h < 8; ++h)
+      *reinterpret_cast<double2 *>(&piece[piece_at(pi, pk + 4 * h)]) = make_double2(-pr[h].x, -pr[h].y);
+  };
+  v4d xs[NC][8];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const prsrc_t P = panel_rsrc(Sz + row0 + (int64_t)n_pad * ((o + c) * TILE));
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xs[c][t][r] = pbuf_ld(P, row_off, colb * (uint32_t)(16 * t + 4 * r));
+    // the block column's own diagonal blocks: in flight during the products before it
+    DiagBlocks d;
+    diag_blocks_load(d, Sz + (int64_t)(o + c) * TILE * (n_pad + 1), n_pad,
+                     inv_diag + inv_group_elems(n_pad) * z + inv_block_offset(o + c), tid);
+    double2 pr[8];
+    if (c > 0) piece_load(pr, c, 0, 0);
+#pragma unroll
+    for (int cp = 0; cp < c; ++cp)
+#pragma unroll
+      for (int q = 0; q < TILE / TALL_PIECE; ++q) {
+        __syncthreads();                 // every wave is done with the piece before
+        piece_store(pr);
+        __syncthreads();
+        const bool last = cp == c - 1 && q == TILE / TALL_PIECE - 1;
+        if (!last) piece_load(pr, c, q + 1 < TILE / TALL_PIECE ? cp : cp + 1, q + 1 < TILE / TALL_PIECE ? q + 1 : 0);
+        // fragments of k-step ks + 1 are read while the 8 MFMAs of k-step ks issue; the fences keep the
+        // compiler from hoisting a whole piece's reads (128 registers) in front of the loop
+        double fa[2][8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) fa[0][t] = piece[piece_at(16 * t + lr, lk)];
+#pragma unroll
+        for (int ks = 0; ks < TALL_PIECE / 4; ++ks) {
+          if (ks + 1 < TALL_PIECE / 4) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) fa[(ks + 1) & 1][t] = piece[piece_at(16 * t + lr, 4 * (ks + 1) + lk)];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const double x = xs[cp][(TALL_PIECE / 16) * q + (ks >> 2)][ks & 3];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) xs[c][t] = mfma4(fa[ks & 1][t], x, xs[c][t]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    __syncthreads();                     // (the blocks of the column before and the last piece are no longer read)
+    diag_blocks_store(d, blk, tid);
+    __syncthreads();
+    solve16(xs[c], blk, lr, lk);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pbuf_st(P, row_off, colb * (uint32_t)(16 * t + 4 * r), xs[c][t][r]);
+  }
+}
+
+int launch_potrf_rawcopy(hipStream_t st, const double *S, int n_pad, int kb, int oe, int batch, double *raw) {
+  const int rows = (oe - kb - 1) * TILE;
+  if (rows <= 0) return GPIRT_OK;
+  hipLaunchKernelGGL(potrf_rawcopy_kernel, dim3(TILE, batch), dim3(256), 0, st, S, n_pad, kb, rows, raw, 2 * RAW_ELEMS);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+// raw: two [RAW_LD x TILE] buffers per group (2 RAW_ELEMS doubles each group); step kb of the super-panel
+// that begins at block column o reads buffer (kb - o) & 1 and leaves the next step's panel in the other
+int launch_potrf_inpanel(hipStream_t st, double *S, int n_pad, int kb, int o, int oe, int batch,
+                         const double *inv_diag, double *raw) {
+  const int G = (oe - kb - 1) * (TILE / 16);
+  if (G <= 0) return GPIRT_OK;
+  const int ntiles = G * (G + 1) / 2, par = (kb - o) & 1;
+  hipLaunchKernelGGL(potrf_inpanel_kernel, dim3((ntiles + 3) / 4, batch), dim3(256), 0, st, S, n_pad, kb, oe, inv_diag,
+                     raw + par * RAW_ELEMS, raw + (par ^ 1) * RAW_ELEMS, 2 * RAW_ELEMS);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+int launch_potrf_tall(hipStream_t st, double *S, int n_pad, int o, int oe, int batch, const double *inv_diag) {
+  const int rows = n_pad - oe * TILE;
+  if (rows <= 0) return GPIRT_OK;
+  // (a super-panel with rows below it is a whole one: only the last may be narrower)
+  if (oe - o != 4) { set_error("launch_potrf_tall: super-panel of %d block columns with rows below it", oe - o); return GPIRT_ERR_BAD_ARG; }
+  hipLaunchKernelGGL(potrf_tall_kernel<4>, dim3(rows / 64, batch), dim3(256), 0, st, S, n_pad, o, inv_diag);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
 // Completes the inverse of every 128 x 128 diagonal block from its inverted 32 x 32 diagonal
 // blocks (what potrf_diag_kernel<false> leaves): one workgroup per block rebuilds the LDS image
 // (L below, the 32-blocks' inverses transposed above) and runs the same block substitution.

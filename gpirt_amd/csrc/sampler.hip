@@ -2090,7 +2090,8 @@ constexpr int kNoAllocMaxN = GPIRT_POTRF_NOALLOC_MAX_N;                       //
 constexpr int64_t kScrS = (int64_t)kNoAllocMaxN * kNoAllocMaxN;               // padded matrix
 constexpr int64_t kScrInv = ((kNoAllocMaxN / TILE + 3) / 4) * (int64_t)SUP * SUP;  // inverted blocks
 constexpr int64_t kScrInfo = 32;                                              // status word (+ pad)
-constexpr int64_t kScrElems = kScrS + kScrInv + kScrInfo;
+constexpr int64_t kScrRaw = POTRF_RAW_ELEMS;                                  // raw panels of the steps inside a super-panel
+constexpr int64_t kScrElems = kScrS + kScrInv + kScrInfo + kScrRaw;
 constexpr int kMaxDevices = 64;
 }  // namespace
 static __device__ __align__(256) double scratch[kScrElems];
@@ -2142,13 +2143,14 @@ int gpirt_potrf_noalloc(const double *d_S, int64_t lds, int32_t n, double *d_L, 
   const int np = (int)pad_up(n);
   double *S = base, *inv = base + kScrS;
   int *info = reinterpret_cast<int *>(base + kScrS + kScrInv);
+  double *raw = base + kScrS + kScrInv + kScrInfo;      // written before it is read in every call
   // the array keeps the last call's contents: the inverted blocks' upper halves are never
   // written and must read zero, the status word must start clear, S is overwritten whole
   GP_HIP(hipMemsetAsync(inv, 0, sizeof(double) * (size_t)inv_group_elems(np), st));
   GP_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
   hipLaunchKernelGGL(pad_in_kernel, dim3((np + 255) / 256, np), dim3(256), 0, st, d_S, lds, n, S, np);
   GP_HIP(hipGetLastError());
-  GP_TRY(launch_potrf(st, S, np, 1, inv, info, nullptr, nullptr, POTRF_DEFER_INVERSES | POTRF_SUBSTITUTION));
+  GP_TRY(launch_potrf(st, S, np, 1, inv, info, raw, nullptr, POTRF_DEFER_INVERSES | POTRF_SUBSTITUTION));
   hipLaunchKernelGGL(tril_out_kernel, dim3((n + 255) / 256, n), dim3(256), 0, st, S, np, n, d_L, ldl);
   GP_HIP(hipGetLastError());
   int h_info = 0;
