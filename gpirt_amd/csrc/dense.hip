@@ -1004,7 +1004,9 @@ int launch_block_inverses(hipStream_t st, const double *S, int n_pad, int batch,
 int launch_potrf_rawcopy(hipStream_t st, const double *S, int n_pad, int kb, int oe, int batch, double *raw);
 int launch_potrf_inpanel(hipStream_t st, double *S, int n_pad, int kb, int o, int oe, int batch,
                          const double *inv_diag, double *raw);
-int launch_potrf_tall(hipStream_t st, double *S, int n_pad, int o, int oe, int batch, const double *inv_diag);
+int launch_potrf_diag_tall(hipStream_t st, double *S, int n_pad, int kb, int batch, double *inv_diag, int *d_info,
+                           int o, int oe, int c);
+int launch_potrf_tall_step(hipStream_t st, double *S, int n_pad, int o, int oe, int c, int batch, const double *inv_diag);
 
 // Off-diagonal blocks of the inverted diagonal super-blocks by block substitution: for a
 // lower-triangular [[A,0],[B,C]] the inverse is [[A^-1,0],[-C^-1 B A^-1, C^-1]].
@@ -1100,23 +1102,32 @@ int launch_potrf(hipStream_t st, double *S, int n_pad, int batch, double *inv, i
     return u;
   };
   const bool ahead = hook && hook->side && hook->ev && batch == 1;
-  // The steps of a super-panel with the diagonal super-block first (potrf_diag.hip): per 128 columns the
-  // diagonal kernel and ONE launch for panel solve + update inside the super-block, then one launch for all
-  // rows below.  Measured at n = 10 000: the steps inside the super-block take 14.5 us against 15 + 19, but the launch
-  // for the rows below takes 87 us whatever their number (2112 dependent MFMAs per wave), which is more than those rows
-  // cost in the step-by-step form: factorisation alone 10.9 against 10.2 ms.  So the step-by-step form over all rows
-  // (three launches per step) stays the default; GPIRT_POTRF_STEPWISE=0 selects the form above.
-  static const bool stepwise = !(getenv("GPIRT_POTRF_STEPWISE") && atoi(getenv("GPIRT_POTRF_STEPWISE")) == 0);
+  // The steps of a super-panel with the diagonal super-block FIRST (potrf_diag.hip).  The chain of small kernels
+  // costs what its launches' first loads and stores cost, whatever the number of rows, so per 128 columns it
+  // only touches the rows of the diagonal super-block: the diagonal kernel, then ONE launch for panel solve +
+  // update inside the super-block (potrf_inpanel_kernel).  The rows below the super-block take block column k
+  // (solve, update of the super-panel's later block columns) as extra workgroups of the NEXT diagonal block's
+  // launch: that step needs nothing of the chain beyond diagonal block k and the step inside the super-block,
+  // and the chain does not wait for it; only the last block column's step, the solve alone, is a launch of its
+  // own before the trailing update.  Measured at n = 10 000 (factorisation alone / with look-ahead / sweeps per
+  // second in the default schedule): step-by-step over all rows, three launches per step, 10.2 ms / 8.8 ms /
+  // 55.2; this form 9.6 / 8.4 / 56.3.  Also measured and not kept: all rows below in ONE launch per super-panel
+  // (a row block's chain over the four block columns in registers: 87 us per launch whatever the rows, 2112
+  // dependent MFMAs per wave: 10.9 ms alone), and the steps of the rows below as launches of their own on a
+  // third stream (a 152-register kernel that fits beside the fixed-grid launches of the second stream: the
+  // steps inside the super-block then share the free CUs with it and slow from 20 to 32 us: 56.2).
+  // GPIRT_POTRF_STEPWISE=1 selects the step-by-step form.
+  static const bool stepwise = getenv("GPIRT_POTRF_STEPWISE") && atoi(getenv("GPIRT_POTRF_STEPWISE")) != 0;
   const bool block_first = subst && !stepwise && work != nullptr;
   for (int o = 0; o < nb; o += 4) {
     const int oe = min(o + 4, nb), sp = o / 4;
     if (block_first) {
       GP_TRY(launch_potrf_rawcopy(st, S, n_pad, o, oe, batch, work));
       for (int k = o; k < oe; ++k) {
-        GP_TRY(launch_potrf_diag(st, S, n_pad, k, batch, inv, nb, d_info, false));
+        GP_TRY(launch_potrf_diag_tall(st, S, n_pad, k, batch, inv, d_info, o, oe, k > o ? k - 1 - o : -1));
         GP_TRY(launch_potrf_inpanel(st, S, n_pad, k, o, oe, batch, inv, work));
       }
-      GP_TRY(launch_potrf_tall(st, S, n_pad, o, oe, batch, inv));
+      GP_TRY(launch_potrf_tall_step(st, S, n_pad, o, oe, oe - 1 - o, batch, inv));
     } else {
       for (int k = o; k < oe; ++k) {
         GP_TRY(launch_potrf_diag(st, S, n_pad, k, batch, inv, nb, d_info, !subst));

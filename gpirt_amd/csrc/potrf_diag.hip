@@ -219,15 +219,14 @@ __device__ __forceinline__ void inverse_offdiag(double *T, const double *dinv, i
 // OFFDIAG = false leaves the inverse at its 32 x 32 diagonal blocks: enough for the panel solve by
 // substitution (trsm_panel_kernel), a quarter of the kernel's time saved on the critical path;
 // block_inverse_kernel completes the 128 x 128 inverses later for the callers that multiply by them.
+constexpr int DIAG_LDS_DOUBLES = TILE * XLD + TILE + 2 * SB;    // image, inverted diagonal, pivot-column exchange
+
 template <bool OFFDIAG>
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S, int n_pad, int kb,
-                                                        double *__restrict__ inv_diag, int nb,
-                                                        int *__restrict__ info) {
-  __shared__ __attribute__((aligned(16))) double T[TILE * XLD];
-  __shared__ __attribute__((aligned(16))) double dinv[TILE];
-  __shared__ __attribute__((aligned(16))) double ucol[2 * SB];
+__device__ __forceinline__ void potrf_diag_body(double *__restrict__ lds, double *__restrict__ S, int n_pad, int kb,
+                                                double *__restrict__ inv_diag, int *__restrict__ info, int z) {
+  double *T = lds, *dinv = lds + TILE * XLD, *ucol = dinv + TILE;
   __builtin_amdgcn_s_setprio(3);          // critical path: ahead of any throughput wave on the same SIMD
-  const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double *A = S + (int64_t)n_pad * n_pad * z + (int64_t)kb * TILE * (n_pad + 1);
   double *Inv = inv_diag + inv_group_elems(n_pad) * z + inv_block_offset(kb);   // ld = SUP
@@ -345,6 +344,14 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S,
   STAMP(18);
 }
 
+template <bool OFFDIAG>
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ S, int n_pad, int kb,
+                                                        double *__restrict__ inv_diag, int nb,
+                                                        int *__restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
+  potrf_diag_body<OFFDIAG>(lds, S, n_pad, kb, inv_diag, info, blockIdx.x);
+}
+
 // Panel solve by substitution, L_ik = A_ik L_kk^-T for every block row i > k, from the factor's
 // diagonal block and its inverted 32 x 32 diagonal blocks.  One wave owns 16 rows of the panel and
 // keeps their solution transposed in MFMA accumulators, 8 tiles of (16 panel columns x 16 rows):
@@ -447,12 +454,13 @@ int launch_trsm_panel(hipStream_t st, double *S, int n_pad, int kb, int batch, c
 // of the rest of the super-panel, once per 128 columns) costs what its launches' first loads and
 // stores cost, whatever the number of rows -- so the rows BELOW the diagonal super-block leave the
 // chain: per 128-column step the chain only touches the at most 384 rows of the super-block
-// (potrf_inpanel_kernel: panel solve and update in ONE launch), and all rows below take the whole
-// super-panel in one launch afterwards (potrf_tall_kernel: X = A L_ss^-T by block substitution
-// over the four block columns, a row block's chain kept in registers).
+// (potrf_inpanel_kernel: panel solve and update in ONE launch), and the rows below take each block
+// column as a step of their own (tall_step_body: solve, then update of the super-panel's later
+// block columns) that rides in the NEXT diagonal block's launch (potrf_diag_tall_kernel), beside
+// the one workgroup that factors that block.
 //
-// Both kernels solve 16 rows per wave by the substitution of trsm_panel_kernel, from the same
-// ten 32 x 32 blocks of the diagonal block (here the six blocks below the diagonal are staged
+// Both kinds of step solve 16 rows per wave by the substitution of trsm_panel_kernel, from the
+// same ten 32 x 32 blocks of the diagonal block (here the six blocks below the diagonal are staged
 // NEGATED, which takes the sign flips out of the loops).
 // ---------------------------------------------------------------------------------------------
 struct DiagBlocks { double2 st[TRSM_BLOCKS][2]; };
@@ -647,91 +655,130 @@ __global__ __launch_bounds__(256) void potrf_inpanel_kernel(double *__restrict__
   }
 }
 
-// All rows below the diagonal super-block [o, o + nc) take the whole super-panel in one launch:
-// X = A L_ss^-T by block substitution over the nc block columns,
-//   X_c = (A_c - sum_{c' < c} X_c' L_cc'^T) L_cc^-T.
-// A workgroup owns 64 rows, a wave 16 of them, whose chain stays in registers from the first block
-// column to the last (the solved blocks are the second operands of the later blocks' products as
-// they stand in the accumulators).  The factors are shared by every workgroup and come through
-// LDS: L_cc' NEGATED, in pieces of 32 columns (the next piece's loads are in flight during the
-// current piece's 64 MFMAs per wave), and the ten 32 x 32 blocks of L_cc for the substitution.
+// pieces of a factor block staged through LDS: 128 rows x 32 columns, element (i, k) at piece_at(i, k)
 constexpr int TALL_PIECE = 32;
 __device__ __forceinline__ int piece_at(int i, int k) { return k * TILE + (i ^ ((k & 1) << 4)); }
 
-template <int NC>
-__global__ __launch_bounds__(256) void potrf_tall_kernel(double *__restrict__ S, int n_pad, int o,
-                                                         const double *__restrict__ inv_diag) {
-  __shared__ __attribute__((aligned(16))) double blk[TRSM_BLOCKS][SB * SB];
-  __shared__ __attribute__((aligned(16))) double piece[TILE * TALL_PIECE];
-  __builtin_amdgcn_s_setprio(2);
-  const int z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// One block column of the same chain as its own step, right-looking: the 64 rows of workgroup `wg`
+// below the diagonal super-block [o, o + nc) solve block column o + c, X_c = A_c L_cc^-T, and update the
+// block columns after it, A_c'' -= X_c L_c''c^T (c'' > c), whose blocks L_c''c the step inside the
+// super-block has just written.  The step needs the factored diagonal block o + c and nothing of the
+// later steps: it runs beside the NEXT diagonal block's kernel, in the same launch
+// (potrf_diag_tall_kernel), so the chain does not wait for it -- and the heaviest step is the first,
+// the lightest (the solve alone) the one that is left over behind the last diagonal block.
+__device__ __forceinline__ void tall_step_body(double *__restrict__ lds, double *__restrict__ S, int n_pad, int o, int nc,
+                                               int c, const double *__restrict__ inv_diag, int z, int wg) {
+  double (*blk)[SB * SB] = reinterpret_cast<double (*)[SB * SB]>(lds);
+  double *piece = lds + TRSM_BLOCKS * SB * SB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double *Sz = S + (int64_t)n_pad * n_pad * z;
-  const int row0 = (o + NC) * TILE + 64 * blockIdx.x + 16 * wave;
-  // staging of a piece: thread t carries rows (2 (t & 63), +1) of columns (t >> 6) + 4 h, h = 0..7
+  const int row0 = (o + nc) * TILE + 64 * wg + 16 * wave;
   const int pi = (tid & 63) << 1, pk = tid >> 6;
-  const uint32_t colb = (uint32_t)n_pad * 8u;            // bytes per column: every offset below stays under 128 columns
+  const uint32_t colb = (uint32_t)n_pad * 8u;
   const uint32_t piece_off = (uint32_t)pi * 8u + colb * (uint32_t)pk, row_off = (uint32_t)lr * 8u + colb * (uint32_t)lk;
-  auto piece_load = [&](double2 (&pr)[8], int c, int cp, int q) {
-    const prsrc_t rs = panel_rsrc(Sz + (int64_t)(o + c) * TILE + (int64_t)n_pad * ((o + cp) * TILE + TALL_PIECE * q));
+  // piece q of L[block row o + cc, block column o + c]: 128 rows x 32 columns
+  auto piece_load = [&](double2 (&pr)[8], int cc, int q) {
+    const prsrc_t rs = panel_rsrc(Sz + (int64_t)(o + cc) * TILE + (int64_t)n_pad * ((o + c) * TILE + TALL_PIECE * q));
 #pragma unroll
     for (int h = 0; h < 8; ++h) pr[h] = pbuf_ld2(rs, piece_off, colb * (uint32_t)(4 * h));
   };
-  auto piece_store = [&](const double2 (&pr)[8]) {
+  const prsrc_t P = panel_rsrc(Sz + row0 + (int64_t)n_pad * ((o + c) * TILE));
+  v4d x[8];
 #pragma unroll
-    for (int h = 0; h < 8; ++h)
-      *reinterpret_cast<double2 *>(&piece[piece_at(pi, pk + 4 * h)]) = make_double2(-pr[h].x, -pr[h].y);
-  };
-  v4d xs[NC][8];
+  for (int t = 0; t < 8; ++t)
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const prsrc_t P = panel_rsrc(Sz + row0 + (int64_t)n_pad * ((o + c) * TILE));
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xs[c][t][r] = pbuf_ld(P, row_off, colb * (uint32_t)(16 * t + 4 * r));
-    // the block column's own diagonal blocks: in flight during the products before it
+    for (int r = 0; r < 4; ++r) x[t][r] = pbuf_ld(P, row_off, colb * (uint32_t)(16 * t + 4 * r));
+  {
     DiagBlocks d;
     diag_blocks_load(d, Sz + (int64_t)(o + c) * TILE * (n_pad + 1), n_pad,
                      inv_diag + inv_group_elems(n_pad) * z + inv_block_offset(o + c), tid);
-    double2 pr[8];
-    if (c > 0) piece_load(pr, c, 0, 0);
-#pragma unroll
-    for (int cp = 0; cp < c; ++cp)
-#pragma unroll
-      for (int q = 0; q < TILE / TALL_PIECE; ++q) {
-        __syncthreads();                 // every wave is done with the piece before
-        piece_store(pr);
-        __syncthreads();
-        const bool last = cp == c - 1 && q == TILE / TALL_PIECE - 1;
-        if (!last) piece_load(pr, c, q + 1 < TILE / TALL_PIECE ? cp : cp + 1, q + 1 < TILE / TALL_PIECE ? q + 1 : 0);
-        // fragments of k-step ks + 1 are read while the 8 MFMAs of k-step ks issue; the fences keep the
-        // compiler from hoisting a whole piece's reads (128 registers) in front of the loop
-        double fa[2][8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) fa[0][t] = piece[piece_at(16 * t + lr, lk)];
-#pragma unroll
-        for (int ks = 0; ks < TALL_PIECE / 4; ++ks) {
-          if (ks + 1 < TALL_PIECE / 4) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) fa[(ks + 1) & 1][t] = piece[piece_at(16 * t + lr, 4 * (ks + 1) + lk)];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          const double x = xs[cp][(TALL_PIECE / 16) * q + (ks >> 2)][ks & 3];
-#pragma unroll
-          for (int t = 0; t < 8; ++t) xs[c][t] = mfma4(fa[ks & 1][t], x, xs[c][t]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    __syncthreads();                     // (the blocks of the column before and the last piece are no longer read)
     diag_blocks_store(d, blk, tid);
-    __syncthreads();
-    solve16(xs[c], blk, lr, lk);
+  }
+  double2 pr[8];
+  if (c + 1 < nc) piece_load(pr, c + 1, 0);
+  __syncthreads();
+  solve16(x, blk, lr, lk);
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pbuf_st(P, row_off, colb * (uint32_t)(16 * t + 4 * r), x[t][r]);
+  for (int cc = c + 1; cc < nc; ++cc) {
+    const prsrc_t Q = panel_rsrc(Sz + row0 + (int64_t)n_pad * ((o + cc) * TILE));
+    v4d w[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pbuf_st(P, row_off, colb * (uint32_t)(16 * t + 4 * r), xs[c][t][r]);
+      for (int r = 0; r < 4; ++r) w[t][r] = pbuf_ld(Q, row_off, colb * (uint32_t)(16 * t + 4 * r));
+#pragma unroll
+    for (int q = 0; q < TILE / TALL_PIECE; ++q) {
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < 8; ++h)
+        *reinterpret_cast<double2 *>(&piece[piece_at(pi, pk + 4 * h)]) = make_double2(-pr[h].x, -pr[h].y);
+      __syncthreads();
+      const bool last = cc == nc - 1 && q == TILE / TALL_PIECE - 1;
+      if (!last) piece_load(pr, q + 1 < TILE / TALL_PIECE ? cc : cc + 1, q + 1 < TILE / TALL_PIECE ? q + 1 : 0);
+      // fragments of k-step ks + 1 are read while the 8 MFMAs of k-step ks issue
+      double fa[2][8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) fa[0][t] = piece[piece_at(16 * t + lr, lk)];
+#pragma unroll
+      for (int ks = 0; ks < TALL_PIECE / 4; ++ks) {
+        if (ks + 1 < TALL_PIECE / 4) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) fa[(ks + 1) & 1][t] = piece[piece_at(16 * t + lr, 4 * (ks + 1) + lk)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const double xv = x[(TALL_PIECE / 16) * q + (ks >> 2)][ks & 3];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) w[t] = mfma4(fa[ks & 1][t], xv, w[t]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pbuf_st(Q, row_off, colb * (uint32_t)(16 * t + 4 * r), w[t][r]);
   }
+}
+
+constexpr int TALL_LDS_DOUBLES = TRSM_BLOCKS * SB * SB + TILE * TALL_PIECE;
+
+// workgroup 0 of a group: the diagonal block kb; the others: step c of the rows below the super-block
+__global__ __launch_bounds__(256) void potrf_diag_tall_kernel(double *__restrict__ S, int n_pad, int kb,
+                                                             double *__restrict__ inv_diag, int *__restrict__ info,
+                                                             int o, int nc, int c) {
+  static_assert(TALL_LDS_DOUBLES <= DIAG_LDS_DOUBLES, "one buffer serves both roles");
+  __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
+  if (blockIdx.x == 0) potrf_diag_body<false>(lds, S, n_pad, kb, inv_diag, info, blockIdx.y);
+  else { __builtin_amdgcn_s_setprio(2); tall_step_body(lds, S, n_pad, o, nc, c, inv_diag, blockIdx.y, blockIdx.x - 1); }
+}
+
+__global__ __launch_bounds__(256) void potrf_tall_step_kernel(double *__restrict__ S, int n_pad, int o, int nc, int c,
+                                                             const double *__restrict__ inv_diag) {
+  __shared__ __attribute__((aligned(16))) double lds[TALL_LDS_DOUBLES];
+  __builtin_amdgcn_s_setprio(3);
+  tall_step_body(lds, S, n_pad, o, nc, c, inv_diag, blockIdx.y, blockIdx.x);
+}
+
+// diagonal block kb beside step c of the rows below the super-block [o, oe) (c < 0: none)
+int launch_potrf_diag_tall(hipStream_t st, double *S, int n_pad, int kb, int batch, double *inv_diag, int *d_info,
+                           int o, int oe, int c) {
+  const int rows = n_pad - oe * TILE;
+  const int tall = c >= 0 && rows > 0 ? rows / 64 : 0;
+  hipLaunchKernelGGL(potrf_diag_tall_kernel, dim3(1 + tall, batch), dim3(256), 0, st, S, n_pad, kb, inv_diag, d_info,
+                     o, oe - o, c);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
+int launch_potrf_tall_step(hipStream_t st, double *S, int n_pad, int o, int oe, int c, int batch, const double *inv_diag) {
+  const int rows = n_pad - oe * TILE;
+  if (rows <= 0) return GPIRT_OK;
+  hipLaunchKernelGGL(potrf_tall_step_kernel, dim3(rows / 64, batch), dim3(256), 0, st, S, n_pad, o, oe - o, c, inv_diag);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
 }
 
 int launch_potrf_rawcopy(hipStream_t st, const double *S, int n_pad, int kb, int oe, int batch, double *raw) {
@@ -751,16 +798,6 @@ int launch_potrf_inpanel(hipStream_t st, double *S, int n_pad, int kb, int o, in
   const int ntiles = G * (G + 1) / 2, par = (kb - o) & 1;
   hipLaunchKernelGGL(potrf_inpanel_kernel, dim3((ntiles + 3) / 4, batch), dim3(256), 0, st, S, n_pad, kb, oe, inv_diag,
                      raw + par * RAW_ELEMS, raw + (par ^ 1) * RAW_ELEMS, 2 * RAW_ELEMS);
-  GP_HIP(hipGetLastError());
-  return GPIRT_OK;
-}
-
-int launch_potrf_tall(hipStream_t st, double *S, int n_pad, int o, int oe, int batch, const double *inv_diag) {
-  const int rows = n_pad - oe * TILE;
-  if (rows <= 0) return GPIRT_OK;
-  // (a super-panel with rows below it is a whole one: only the last may be narrower)
-  if (oe - o != 4) { set_error("launch_potrf_tall: super-panel of %d block columns with rows below it", oe - o); return GPIRT_ERR_BAD_ARG; }
-  hipLaunchKernelGGL(potrf_tall_kernel<4>, dim3(rows / 64, batch), dim3(256), 0, st, S, n_pad, o, inv_diag);
   GP_HIP(hipGetLastError());
   return GPIRT_OK;
 }

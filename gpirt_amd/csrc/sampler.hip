@@ -223,6 +223,7 @@ static void sampler_free(gpirt_sampler *s) {
   for (hipEvent_t e : s->upd_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_panel) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_ahead) (void)hipEventDestroy(e);
+
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->ev_z) (void)hipEventDestroy(s->ev_z);
   if (s->ev_pref) (void)hipEventDestroy(s->ev_pref);

@@ -4,7 +4,9 @@ The library picks its GEMM and panel-solve kernels once per process (environment
 first use), so each variant runs in a child process of its own: the LDS-staged GEMM for every
 product (`GPIRT_GEMM_LDS=1`, the default for transposed-A products only), the LDS-staged small-tile
 GEMM (`GPIRT_SMALL_DIRECT=0`) and the panel solve as a product with the inverted diagonal block
-(`GPIRT_NO_SUBSTITUTION=1`).  The child calls the parity tests of tests/test_gpu_parity.py as
+(`GPIRT_NO_SUBSTITUTION=1`), and the factorisation's steps in their step-by-step form over all rows
+(`GPIRT_POTRF_STEPWISE=1`: diagonal block, panel solve, update as three launches per 128 columns; the
+default takes the diagonal super-block first).  The child calls the parity tests of tests/test_gpu_parity.py as
 plain functions."""
 import os
 import sys
@@ -35,8 +37,9 @@ def _child(rank, env):
 
 
 @pytest.mark.parametrize("env", [{"GPIRT_GEMM_LDS": "1"},
-                                 {"GPIRT_SMALL_DIRECT": "0", "GPIRT_NO_SUBSTITUTION": "1"}],
-                         ids=["lds_gemm", "lds_small_gemm_and_inverse_panel_solve"])
+                                 {"GPIRT_SMALL_DIRECT": "0", "GPIRT_NO_SUBSTITUTION": "1"},
+                                 {"GPIRT_POTRF_STEPWISE": "1"}],
+                         ids=["lds_gemm", "lds_small_gemm_and_inverse_panel_solve", "stepwise_factorisation"])
 def test_variant_kernels_match_the_oracle(env):
     import torch.multiprocessing as mp
     mp.spawn(_child, args=(env,), nprocs=1, join=True)
