@@ -639,7 +639,11 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     const bool tail = !(tl && atoi(tl) == 0);
     int k = (s->nb - 512 / ncol + 3) / 4;
     k = max((nsup + 1) / 2, min(k, nsup - 2));
-    if (tail && k > 2) --k;     // with the last rows' early panels taken beside the factorisation too, one super-panel fewer
+    // with the last rows' early panels taken beside the factorisation too, fewer super-panels of rows: one fewer with
+    // the factorisation's step-by-step form, two fewer since its steps take the diagonal super-block first (the chain
+    // of small kernels is shorter and the chunks lag more: n = 10 000, m = 4096: 15 super-panels + 14 panels 56.2,
+    // 14 + 13 57.0, 14 + 12 57.3, 13 + 12 54.5, 16 + 15 53.3 sweeps/s)
+    if (tail && k > 3) k -= 2;
     s->nu_overlap = max(0, e ? min(atoi(e), nsup) : k);
     ov_forced = e != nullptr;
     s->nu_chunk = c ? max(1, atoi(c)) : max(1, min(16, 224 / ncol));
