@@ -56,6 +56,9 @@ __device__ inline double phi_upper(double z, const double *s) {   // Phi(-z), z 
   // centre of the interval: the same high word with the lower mantissa bits replaced by 100..0
   const double t = w - __hiloint2double((hi & ~((1 << (20 - PHI_S)) - 1)) | (1 << (19 - PHI_S)), 0);
   int row = k * (PHI_LD * 8);
+#ifdef GPIRT_PROBE_SAME_ROW
+  row = 100 * (PHI_LD * 8);
+#endif
   asm volatile("" : "+v"(row));               // one address, three immediate offsets
   // 16-byte LDS reads move 256 bytes per clock, the 8-byte pairs (ds_read2_b64) half of that
   const double2 *c = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s) + row);
@@ -75,14 +78,18 @@ __device__ inline double phi_upper(double z, const double *s) {   // Phi(-z), z 
 // P(zlo < Z <= zhi) from the two tails e1 = Phi(-|zlo|), e2 = Phi(-|zhi|) (zlo, zhi already
 // clamped to finite values), floored so that a vanished cell stays finite
 __device__ inline double ordinal_cell_from_tails(double zlo, double zhi, double e1, double e2) {
-  double p = zlo >= 0.0 ? e1 - e2 : (zhi <= 0.0 ? e2 - e1 : (1.0 - e1) - e2);
+  // both thresholds on one side of zero: e1 - e2 (zlo >= 0) or e2 - e1 (zhi <= 0), and whichever applies is
+  // the positive one of the two (the tail decreases in |z|), i.e. |e1 - e2| exactly; thresholds on both sides:
+  // (1 - e1) - e2.  As two sums and one select: written as a chain of conditionals it compiled to divergent
+  // branches in the middle of the row loops.
+  const double same_side = fabs(e1 - e2), across = (1.0 - e1) - e2;
+  double p = (zlo < 0.0 && zhi > 0.0) ? across : same_side;
   if (!(p > kPFloor)) p = kPFloor;
   return p;
 }
 
 __device__ inline double ordinal_cell_prob(double zlo, double zhi, const double *s) {
-  zlo = fmax(zlo, -1e30);                      // +-inf thresholds: keep the arithmetic finite
-  zhi = fmin(zhi, 1e30);
+  // (an end category's threshold is -+inf: phi_upper cuts |z| at 40, the comparisons above take infinities)
   return ordinal_cell_from_tails(zlo, zhi, phi_upper(fabs(zlo), s), phi_upper(fabs(zhi), s));
 }
 
