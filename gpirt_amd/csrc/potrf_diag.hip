@@ -119,6 +119,18 @@ __device__ __forceinline__ void store_l_columns(const double *T, double *A, int 
         make_double2(i2 >= c ? T[i2 * XLD + c] : 0.0, i2 + 1 >= c ? T[(i2 + 1) * XLD + c] : 0.0);
 }
 
+// The inverted 32 x 32 diagonal block b of the image (transposed above the diagonal, its diagonal in dinv)
+// to the inverse image in global memory, lower triangle only; the work of wave `part` of `nparts`.
+__device__ __forceinline__ void store_inv_block(const double *T, const double *dinv, double *Inv, int b, int part,
+                                                int nparts, int lane) {
+  for (int idx = part * 64 + lane; idx < 16 * SB; idx += nparts * 64) {
+    const int rp = idx & 15, c = idx >> 4;               // rows 2 rp, 2 rp + 1 and column c of the block
+    const int i = SB * b + 2 * rp, cc = SB * b + c;
+    if (c <= 2 * rp + 1)
+      *reinterpret_cast<double2 *>(Inv + i + SUP * cc) = make_double2(x_sel(T, dinv, i, cc), x_sel(T, dinv, i + 1, cc));
+  }
+}
+
 // Off-diagonal blocks of X = L^-1 in the LDS image (L in the lower triangle, the inverted
 // 32 x 32 diagonal blocks transposed above it, their diagonals in dinv), for all four waves of the
 // workgroup.  Ends with a barrier.
@@ -232,21 +244,24 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ lds, double
   double *Inv = inv_diag + inv_group_elems(n_pad) * z + inv_block_offset(kb);   // ld = SUP
   STAMP(0);
 
-  // block in: 16 independent 16-byte loads per thread are issued before the first is used
+  // block in, lower triangle only (an entry above the diagonal is stored as zero without being loaded).
+  // First the 32 columns that the factorisation of the first 32 x 32 block and its panel read, by all four
+  // waves; the other 96 columns come in beside that factorisation, on the three waves that have nothing
+  // else to do then.  All loads of a batch are issued before the first is used.
+  const int i2 = (tid & 63) * 2;                        // this thread's rows i2, i2 + 1
   {
-    const int i2 = (tid & 63) * 2, cq = tid >> 6;       // rows i2, i2+1 of columns cq + 4*s
+    const int cq = tid >> 6;                            // columns cq + 4 s
+    double2 v[8];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      double2 v[16];
+    for (int s2 = 0; s2 < 8; ++s2) {
+      const int c = cq + 4 * s2;
+      v[s2] = i2 + 1 >= c ? *reinterpret_cast<const double2 *>(A + i2 + (int64_t)n_pad * c) : make_double2(0.0, 0.0);
+    }
 #pragma unroll
-      for (int s2 = 0; s2 < 16; ++s2)
-        v[s2] = *reinterpret_cast<const double2 *>(A + i2 + (int64_t)n_pad * (cq + 4 * (s2 + 16 * half)));
-#pragma unroll
-      for (int s2 = 0; s2 < 16; ++s2) {
-        const int c = cq + 4 * (s2 + 16 * half);
-        T[i2 * XLD + c] = (i2 >= c) ? v[s2].x : 0.0;
-        T[(i2 + 1) * XLD + c] = (i2 + 1 >= c) ? v[s2].y : 0.0;
-      }
+    for (int s2 = 0; s2 < 8; ++s2) {
+      const int c = cq + 4 * s2;
+      T[i2 * XLD + c] = (i2 >= c) ? v[s2].x : 0.0;
+      T[(i2 + 1) * XLD + c] = (i2 + 1 >= c) ? v[s2].y : 0.0;
     }
   }
   __syncthreads();
@@ -279,13 +294,38 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ lds, double
         const int own = ((int)(c > r) ^ half) ^ 1;            // low half: c <= r, high half: c > r
         Trow[own ? i0 + c : TILE + half] = x[c];
       }
-    } else if (p > 0) {
+    } else if (p == 0) {
+      // columns 32..127 of the block: wave w takes columns 32 + (w - 1) + 3 s
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        double2 v[16];
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          const int c = SB + (wave - 1) + 3 * (s2 + 16 * half);
+          v[s2] = i2 + 1 >= c ? *reinterpret_cast<const double2 *>(A + i2 + (int64_t)n_pad * c) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          const int c = SB + (wave - 1) + 3 * (s2 + 16 * half);
+          T[i2 * XLD + c] = (i2 >= c) ? v[s2].x : 0.0;
+          T[(i2 + 1) * XLD + c] = (i2 + 1 >= c) ? v[s2].y : 0.0;
+        }
+      }
+    } else {
       // beside the factorisation of block p, on the other three SIMDs: what is left of step p-1
-      // (its three tiles that make up block p were waited for) and the store of column block
-      // p-1, which is final.  None of it touches block p or reads what wave 0 writes.
+      // (its three tiles that make up block p were waited for).  None of it touches block p or reads
+      // what wave 0 writes.
       const int j0 = i0 - SB, NTq = (TILE - j0 - SB) / 16;
       for (int e = 3 + (wave - 1); e < NTq * (NTq + 1) / 2; e += 3) trailing_tile(T, j0, e, lr, lk);
-      store_l_columns(T, A, n_pad, j0, wave - 1, 3, lane);
+      // The finished column blocks of L, and (without the off-diagonal blocks of the inverse, when nothing else
+      // of the inverse image is written) the inverted diagonal blocks, leave from here.  Beside block 1 these
+      // waves have the most tiles of all steps (18) and already outlast the factorisation: what block 0
+      // finished waits for the step after.
+      if (p >= 2)
+        for (int q = p == 2 ? 0 : 2; q < p; ++q) {
+          store_l_columns(T, A, n_pad, q * SB, wave - 1, 3, lane);
+          if (!OFFDIAG) store_inv_block(T, dinv, Inv, q, wave - 1, 3, lane);
+        }
     }
     __syncthreads();
     STAMP(2 + 3 * p);
@@ -330,16 +370,18 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ lds, double
   if (OFFDIAG) inverse_offdiag(T, dinv, wave, lr, lk);
   STAMP(17);
 
-  {
-    const int i2 = (tid & 63) * 2, cq = tid >> 6;
+  if (OFFDIAG) {
+    const int cq = tid >> 6;
 #pragma unroll 8
     for (int s2 = 0; s2 < 32; ++s2) {
       const int c = cq + 4 * s2;
       // the inverse image's strict upper triangle is zero from its allocation on and stays so
-      if (c <= i2 + 1 && (OFFDIAG || c >= (i2 & ~(SB - 1))))
+      if (c <= i2 + 1)
         *reinterpret_cast<double2 *>(Inv + i2 + SUP * c) =
             make_double2(x_sel(T, dinv, i2, c), x_sel(T, dinv, i2 + 1, c));
     }
+  } else {
+    store_inv_block(T, dinv, Inv, TILE / SB - 1, wave, 4, lane);
   }
   STAMP(18);
 }
