@@ -13,8 +13,10 @@ constexpr int SB = 32;          // inner block size
 #ifdef DIAG_STAMPS
 __device__ long long g_diag_stamps[32];
 #define STAMP(i) do { if (threadIdx.x == 0) g_diag_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define STAMP1(i) do { if (threadIdx.x == 64) g_diag_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMP1(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ v4d mfma4(double a, double b, v4d c) {
@@ -294,8 +296,10 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ lds, double
         const int own = ((int)(c > r) ^ half) ^ 1;            // low half: c <= r, high half: c > r
         Trow[own ? i0 + c : TILE + half] = x[c];
       }
+      if (p == 0) STAMP(23);
     } else if (p == 0) {
       // columns 32..127 of the block: wave w takes columns 32 + (w - 1) + 3 s
+      STAMP1(20);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         double2 v[16];
@@ -310,6 +314,7 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ lds, double
           T[i2 * XLD + c] = (i2 >= c) ? v[s2].x : 0.0;
           T[(i2 + 1) * XLD + c] = (i2 + 1 >= c) ? v[s2].y : 0.0;
         }
+        STAMP1(21 + half);
       }
     } else {
       // beside the factorisation of block p, on the other three SIMDs: what is left of step p-1

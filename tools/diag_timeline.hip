@@ -26,5 +26,7 @@ int main() {
   hipMemcpyFromSymbol(st, HIP_SYMBOL(gpirt::g_diag_stamps), sizeof(st));
   for (int i = 1; i < 19; ++i) if (st[i] && st[i - 1]) printf("%-14s %8lld clocks\n", names[i], st[i] - st[i - 1]);
   printf("total %lld clocks\n", st[18] - st[0]);
+  printf("from the first barrier: wave 1 begins its columns %lld, first batch done %lld, second %lld; wave 0 ends its factorisation %lld\n",
+         st[20] - st[1], st[21] - st[1], st[22] - st[1], st[23] - st[1]);
   return 0;
 }
