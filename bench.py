@@ -71,12 +71,15 @@ def substeps(n, m, C, G, ms, evals, r0=0, lookahead=False, k0=0):
     return out
 
 
+PMC_FILE = "r03_pmc_kernels.json"
+
+
 def pmc_record():
-    """The committed rocprofv3 PMC passes (profiles/r02_pmc_kernels.json: FETCH_SIZE doubled as the
+    """The committed rocprofv3 PMC passes (profiles/PMC_FILE: FETCH_SIZE doubled as the
     gfx950 correction asks, plus WRITE_SIZE, separate passes; counters cannot be read from inside
     this process).  Valid for the benchmark's own configuration on one GPU only."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")))
+        return json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
     except OSError:
         return None
 
@@ -469,8 +472,8 @@ def main():
                 "algorithmic_bytes_per_launch": ((upd_fl / upd_n) / (2.0 * 128 * 128 * 512) * (2 * 128 * 128 * 8)
                                                  if upd_n else 0.0),
                 "traffic": upd_pmc["hbm_bytes_per_launch"] if upd_pmc else None,
-                "traffic_note": "mean HBM bytes per launch of this kernel from profiles/r02_pmc_kernels.json "
-                                "(rocprofv3 --pmc, 2 x FETCH_SIZE + WRITE_SIZE); algorithmic = read + write of "
+                "traffic_note": "mean HBM bytes per launch of this kernel from profiles/" + PMC_FILE +
+                                " (rocprofv3 --pmc, 2 x FETCH_SIZE + WRITE_SIZE); algorithmic = read + write of "
                                 "each lower tile of the trailing matrix once (the 512-wide panel is re-read from cache)",
                 "other_instances": {
                     "nu_after_factorisation": {
@@ -521,7 +524,7 @@ def main():
                               "valu_issue_cycles_share_of_wave_cycles": k.get("valu_active_share_of_wave_cycles")}
         if lik:
             out["likelihood_kernels_measured"] = {
-                "source": "profiles/r02_pmc_kernels.json (rocprofv3 --pmc passes of this benchmark; durations and "
+                "source": "profiles/" + PMC_FILE + " (rocprofv3 --pmc passes of this benchmark; durations and "
                           "rates are those under the profiler, which serialises kernels and lowers the clock)",
                 "bound": "FP64 VALU issue and LDS gathers of the Mills-ratio table, not HBM: see valu_issue_cycles_share", "kernels": lik}
         if variant is not None:
