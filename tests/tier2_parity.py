@@ -140,6 +140,8 @@ def run_mid_rung(n=2500, m=1024, C=5, burn=100, sample=100, seed=1):
         if it >= burn:
             sum_g += tg
             sum_c += tc
+        if (it + 1) % 20 == 0:
+            print("mid rung: sweep %d of %d, cpu %.1f s" % (it + 1, burn + sample, t_cpu), file=sys.stderr, flush=True)
     dg, dc = g.diagnostics(), c.diagnostics()
     g.close(); c.close()
     th_g, th_c = sum_g / sample, sum_c / sample
@@ -182,7 +184,10 @@ def check(row):
 
 
 if __name__ == "__main__":
-    rows = [run_fixture(stem, C) for stem, C in FIXTURES]
+    rows = []
+    for stem, C in FIXTURES:
+        rows.append(run_fixture(stem, C))
+        print("fixture %s done: %s" % (stem, rows[-1]["seconds"]), file=sys.stderr, flush=True)
     mid = run_mid_rung()
     table = dict(settings="gpirt-sythetic.R:60-94: 500 + 500 sweeps, THIN 4, theta_init = theta + 0.05 N(0,1), "
                           "theta_ls = H/2, RBF, thresholds sampled, constant_IRF = 0",
