@@ -179,9 +179,15 @@ __device__ inline bool surely_rejected(int e, double hh, int *redi, int w) {
 // offset: the load then takes the base from scalar registers and one vector register of offset
 // (a 64-bit index costs four extra vector instructions per load).
 __device__ inline double col_at(const double *base, uint32_t r) {
+#ifdef GPIRT_PROBE_SHORT_COLUMN
+  r &= 1023;                                           // timing probe: every pass hits the cache (wrong numbers)
+#endif
   return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (r << 3));
 }
 __device__ inline int col_at(const int8_t *base, uint32_t r) {
+#ifdef GPIRT_PROBE_SHORT_COLUMN
+  r &= 1023;
+#endif
   return *reinterpret_cast<const int8_t *>(reinterpret_cast<const char *>(base) + r);
 }
 
