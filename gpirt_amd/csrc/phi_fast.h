@@ -3,7 +3,7 @@
 // log( Phi(zhi) - Phi(zlo) )  (log_like_fn.m:3-4 with the probit link of sigmoid_fn.m:4,
 // ordinal form gpirt-sythetic.R:159-167) from two evaluations of the upper tail
 //   Phi(-z) = exp(-z^2/2) * g(z),  z >= 0,
-// where g is read from a table of degree-6 polynomials (phi_table.h, relative error <= 5e-16 on
+// where g is read from a table of degree-5 polynomials (phi_table.h, relative error <= 5e-16 on
 // [0,40]) whose interval number and local variable are cut out of the bits of z + 1: no
 // division (v_rcp_f64 alone costs as much as 3.4 fused multiply-adds, its Newton steps 4 more).
 // No data-dependent branch: the library erfc picks one of several code paths per lane, and a
@@ -17,11 +17,11 @@
 namespace gpirt {
 
 constexpr int PHI_ROWS = GPIRT_PHI_K;
-constexpr int PHI_NC = 6;        // doubles per row: c0..c4 and the two floats c5, c6 in the sixth
+constexpr int PHI_NC = 6;        // doubles per row: c0..c5
 constexpr int PHI_LD = PHI_NC;   // LDS row stride: 48-byte rows, three 16-byte reads, 16 bank positions
 constexpr int PHI_S = GPIRT_PHI_S;
 
-constexpr int EXP_TAB = 64;  // 2^(j/64), j = 0..63, behind the polynomial table
+constexpr int EXP_TAB = 256;  // 2^(j/256), j = 0..255, behind the polynomial table
 constexpr int PHI_LDS_DOUBLES = PHI_ROWS * PHI_LD + EXP_TAB;
 
 // every thread of the workgroup calls this once, followed by __syncthreads()
@@ -32,20 +32,23 @@ __device__ inline void phi_table_to_lds(double *s) {
     s[PHI_ROWS * PHI_LD + j] = exp2((double)j * (1.0 / EXP_TAB));
 }
 
-// exp(h + l) for h <= 0 and a tiny correction l: h = (64 m + j) ln2/64 + r with |r| <= ln2/128,
-// 2^(j/64) from the table, exp(r) - 1 from a degree-5 polynomial (remainder 3e-17), scaled
-// by 2^m.  Branch-free; underflows gradually to zero.
-__device__ inline double exp_neg(double h, double l, const double *s) {
-  const double nf = rint(h * 92.33248261689366);               // 64 / ln 2; h >= -800: fits an int with room
-  double r = fma(nf, -0.010830424695086549, h);                 // ln2/64 high part (33 bits: exact product)
-  r = fma(nf, -1.162596423439437e-12, r) + l;                   // low part
+// exp(-z^2/2) for z >= 0: with h = -z^2/2 = (256 m + j) ln2/256 + r, |r| <= ln2/512, 2^(j/256) comes from the
+// table, exp(r) - 1 from a degree-4 polynomial (remainder r^5/120 < 4e-17), scaled by 2^m.  r is formed from
+// the EXACT product: n ln2_hi is exact (a 33-bit constant times an integer below 2^19), and one fused
+// multiply-add takes it from (-z/2) z before that product is ever rounded -- what rounding h first would
+// lose (|h| 2^-53 in the exponent, a relative error of the result that grows with |h|) never arises.
+// Branch-free; underflows gradually to zero.
+__device__ inline double exp_neg_half_square(double z, const double *s) {
+  const double mz = -0.5 * z;
+  const double nf = rint(mz * z * 369.3299304675746);           // 256 / ln 2; z <= 40: fits an int with room
+  double r = fma(mz, z, -(nf * 0.0027076061737716373));         // ln2/256 high part (33 bits: exact product)
+  r = fma(nf, -2.9064910585985925e-13, r);                      // low part
   const int n = (int)nf;
   const double t = s[PHI_ROWS * PHI_LD + (n & (EXP_TAB - 1))];
-  double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
-  q = fma(q, r, 1.0 / 6.0);
+  double q = fma(r, 1.0 / 24.0, 1.0 / 6.0);
   q = fma(q, r, 0.5);
   q = fma(q, r, 1.0);
-  return ldexp(fma(t, q * r, t), n >> 6);
+  return ldexp(fma(t, q * r, t), n >> 8);
 }
 
 __device__ inline double phi_upper(double z, const double *s) {   // Phi(-z), z >= 0
@@ -62,17 +65,13 @@ __device__ inline double phi_upper(double z, const double *s) {   // Phi(-z), z 
   asm volatile("" : "+v"(row));               // one address, three immediate offsets
   // 16-byte LDS reads move 256 bytes per clock, the 8-byte pairs (ds_read2_b64) half of that
   const double2 *c = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s) + row);
-  const double2 c01 = c[0], c23 = c[1], c4p = c[2];
-  double g = (double)__int_as_float(__double2hiint(c4p.y));
-  g = fma(g, t, (double)__int_as_float(__double2loint(c4p.y)));
-  g = fma(g, t, c4p.x);
+  const double2 c01 = c[0], c23 = c[1], c45 = c[2];
+  double g = fma(c45.y, t, c45.x);
   g = fma(g, t, c23.y);
   g = fma(g, t, c23.x);
   g = fma(g, t, c01.y);
   g = fma(g, t, c01.x);
-  const double h = -0.5 * z * z;
-  const double l = fma(-0.5 * z, z, -h);      // rounding error of h, folded into the exponent
-  return exp_neg(h, l, s) * g;
+  return exp_neg_half_square(z, s) * g;
 }
 
 // P(zlo < Z <= zhi) from the two tails e1 = Phi(-|zlo|), e2 = Phi(-|zhi|) (zlo, zhi already

@@ -129,24 +129,30 @@ __global__ __launch_bounds__(256) void theta_table_kernel(ThetaArgs a) {
   __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
   phi_table_to_lds(sphi);
   __syncthreads();
-  const int u = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
   const int U_pad = a.U_pad, C = a.C;
   if (u >= U_pad || u % a.ML >= a.mloc) return;
-  const double xg = a.grid_lo + a.grid_step * g;
-  const double F = a.Gt[u + (int64_t)U_pad * g] + a.betaS[u] + a.betaS[u + U_pad] * xg +
-                   a.betaS[u + 2 * (int64_t)U_pad] * xg * xg;
-  double zlo = -1e30, e1 = phi_upper(1e30, sphi);          // lower end: -inf
-  double *out = a.tab + u + (int64_t)U_pad * C * g;
-  for (int c = 0; c < C; ++c) {
-    const double zhi = c + 1 < C ? fmin(fmax(a.bthrS[u + (int64_t)U_pad * (c + 1)] - F, -1e30), 1e30) : 1e30;
-    const double e2 = phi_upper(fabs(zhi), sphi);
-    out[(int64_t)U_pad * c] = log(ordinal_cell_from_tails(zlo, zhi, e1, e2));
-    zlo = zhi; e1 = e2;
+  const double c0 = a.betaS[u], c1 = a.betaS[u + U_pad], c2 = a.betaS[u + 2 * (int64_t)U_pad];
+  const double e_first = phi_upper(1e30, sphi);            // lower end: -inf
+  // a workgroup stages the tail table once and serves every gridDim.y-th grid point with it
+  for (int g = blockIdx.y; g < a.G; g += gridDim.y) {
+    const double xg = a.grid_lo + a.grid_step * g;
+    const double F = a.Gt[u + (int64_t)U_pad * g] + c0 + c1 * xg + c2 * xg * xg;
+    double zlo = -1e30, e1 = e_first;
+    double *out = a.tab + u + (int64_t)U_pad * C * g;
+    for (int c = 0; c < C; ++c) {
+      const double zhi = c + 1 < C ? fmin(fmax(a.bthrS[u + (int64_t)U_pad * (c + 1)] - F, -1e30), 1e30) : 1e30;
+      const double e2 = phi_upper(fabs(zhi), sphi);
+      out[(int64_t)U_pad * c] = log(ordinal_cell_from_tails(zlo, zhi, e1, e2));
+      zlo = zhi; e1 = e2;
+    }
   }
 }
 
 int launch_theta_table(hipStream_t st, const ThetaArgs &a) {
-  hipLaunchKernelGGL(theta_table_kernel, dim3((a.U_pad + 255) / 256, a.G), dim3(256), 0, st, a);
+  // enough workgroups for two rounds of the chip at four to a CU
+  const int nbx = (a.U_pad + 255) / 256, gy = std::max(1, std::min(a.G, 2048 / nbx));
+  hipLaunchKernelGGL(theta_table_kernel, dim3(nbx, gy), dim3(256), 0, st, a);
   GP_HIP(hipGetLastError());
   return GPIRT_OK;
 }
@@ -479,22 +485,26 @@ __global__ __launch_bounds__(256) void grid_table_kernel(ThetaArgs a, int G_pad,
   __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
   phi_table_to_lds(sphi);
   __syncthreads();
-  const int g = blockIdx.x * blockDim.x + threadIdx.x, jl = blockIdx.y;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= a.G) return;
   const int U_pad = a.U_pad;
   const double xg = a.grid_lo + a.grid_step * g;
-  const double gg = a.Gt[jl + (int64_t)U_pad * g] + a.betaS[jl] + a.betaS[jl + U_pad] * xg +
-                    a.betaS[jl + 2 * (int64_t)U_pad] * xg * xg;
-  double lo = a.bthrS[jl];
-  for (int c = 0; c < a.C; ++c) {
-    const double hi = a.bthrS[jl + (int64_t)U_pad * (c + 1)];
-    T[g + (int64_t)G_pad * (jl + (int64_t)a.ML * c)] = ordinal_cell_fast(lo - gg, hi - gg, sphi);
-    lo = hi;
+  // a workgroup stages the tail table once and serves every gridDim.y-th item with it
+  for (int jl = blockIdx.y; jl < a.mloc; jl += gridDim.y) {
+    const double gg = a.Gt[jl + (int64_t)U_pad * g] + a.betaS[jl] + a.betaS[jl + U_pad] * xg +
+                      a.betaS[jl + 2 * (int64_t)U_pad] * xg * xg;
+    double lo = a.bthrS[jl];
+    for (int c = 0; c < a.C; ++c) {
+      const double hi = a.bthrS[jl + (int64_t)U_pad * (c + 1)];
+      T[g + (int64_t)G_pad * (jl + (int64_t)a.ML * c)] = ordinal_cell_fast(lo - gg, hi - gg, sphi);
+      lo = hi;
+    }
   }
 }
 
 int launch_grid_table(hipStream_t st, const ThetaArgs &a, int G_pad, double *T) {
-  hipLaunchKernelGGL(grid_table_kernel, dim3((a.G + 255) / 256, a.mloc), dim3(256), 0, st, a, G_pad, T);
+  const int nbx = (a.G + 255) / 256, gy = std::max(1, std::min(a.mloc, 2048 / nbx));
+  hipLaunchKernelGGL(grid_table_kernel, dim3(nbx, gy), dim3(256), 0, st, a, G_pad, T);
   GP_HIP(hipGetLastError());
   return GPIRT_OK;
 }
@@ -572,26 +582,30 @@ __global__ __launch_bounds__(256) void summary_prob_kernel(ThetaArgs a, int quad
   __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
   phi_table_to_lds(sphi);
   __syncthreads();
-  const int u = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
   const int U_pad = a.U_pad;
   if (u >= U_pad || u % a.ML >= a.mloc) return;
-  const double xg = a.grid_lo + a.grid_step * g;
-  double F = a.Gt[u + (int64_t)U_pad * g] + a.betaS[u] + a.betaS[u + U_pad] * xg;
-  if (quadratic) F += a.betaS[u + 2 * (int64_t)U_pad] * xg * xg;
-  double lo = a.bthrS[u], best = -1.0;
-  int arg = 1;
-  for (int c = 0; c < a.C; ++c) {
-    const double hi = a.bthrS[u + (int64_t)U_pad * (c + 1)];
-    const double p = ordinal_cell_prob(lo - F, hi - F, sphi);
-    psum[u + (int64_t)U_pad * (c + (int64_t)a.C * g)] += p;
-    if (p > best) { best = p; arg = c + 1; }      // which.max: the first maximum
-    lo = hi;
+  // a workgroup stages the tail table once and serves every gridDim.y-th grid point with it
+  for (int g = blockIdx.y; g < a.G; g += gridDim.y) {
+    const double xg = a.grid_lo + a.grid_step * g;
+    double F = a.Gt[u + (int64_t)U_pad * g] + a.betaS[u] + a.betaS[u + U_pad] * xg;
+    if (quadratic) F += a.betaS[u + 2 * (int64_t)U_pad] * xg * xg;
+    double lo = a.bthrS[u], best = -1.0;
+    int arg = 1;
+    for (int c = 0; c < a.C; ++c) {
+      const double hi = a.bthrS[u + (int64_t)U_pad * (c + 1)];
+      const double p = ordinal_cell_prob(lo - F, hi - F, sphi);
+      psum[u + (int64_t)U_pad * (c + (int64_t)a.C * g)] += p;
+      if (p > best) { best = p; arg = c + 1; }      // which.max: the first maximum
+      lo = hi;
+    }
+    asum[u + (int64_t)U_pad * g] += (double)arg;
   }
-  asum[u + (int64_t)U_pad * g] += (double)arg;
 }
 
 int launch_summary_prob(hipStream_t st, const ThetaArgs &a, int quadratic, double *psum, double *asum) {
-  hipLaunchKernelGGL(summary_prob_kernel, dim3((a.U_pad + 255) / 256, a.G), dim3(256), 0, st, a,
+  const int nbx = (a.U_pad + 255) / 256, gy = std::max(1, std::min(a.G, 2048 / nbx));
+  hipLaunchKernelGGL(summary_prob_kernel, dim3(nbx, gy), dim3(256), 0, st, a,
                      quadratic, psum, asum);
   GP_HIP(hipGetLastError());
   return GPIRT_OK;

@@ -161,7 +161,7 @@ def test_rows_of_nu_beside_the_factorisation_leave_the_chain_unchanged(monkeypat
     for flags, forced, ahead, rows_ok, la_ok in ((0, 12, 0, (12 * 512,), (False,)),
                                                  (0, 12, 1, (12 * 512,), (True,)),
                                                  (_abi.NO_NU_OVERLAP, None, 1, (0,), (True,)),
-                                                 (0, None, None, (0, 15 * 512), (False, True))):
+                                                 (0, None, None, (0, 14 * 512, 17 * 512), (False, True))):
         st, rows, la, dg = chain(flags, forced, ahead)
         assert rows in rows_ok and la in la_ok, (flags, forced, ahead, rows, la)
         assert dg == dg0
