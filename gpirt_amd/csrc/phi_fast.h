@@ -32,23 +32,23 @@ __device__ inline void phi_table_to_lds(double *s) {
     s[PHI_ROWS * PHI_LD + j] = exp2((double)j * (1.0 / EXP_TAB));
 }
 
-// exp(-z^2/2) for z >= 0: with h = -z^2/2 = (256 m + j) ln2/256 + r, |r| <= ln2/512, 2^(j/256) comes from the
-// table, exp(r) - 1 from a degree-4 polynomial (remainder r^5/120 < 4e-17), scaled by 2^m.  r is formed from
-// the EXACT product: n ln2_hi is exact (a 33-bit constant times an integer below 2^19), and one fused
-// multiply-add takes it from (-z/2) z before that product is ever rounded -- what rounding h first would
-// lose (|h| 2^-53 in the exponent, a relative error of the result that grows with |h|) never arises.
-// Branch-free; underflows gradually to zero.
+// exp(-z^2/2) for z >= 0: with z^2 = -(256 m + j) 2 ln2/256 + v, 0 <= j < 256, |v| <= ln2/256, 2^(j/256) comes from
+// the table, exp(-v/2) - 1 from a degree-4 polynomial in v (remainder (v/2)^5/120 < 4e-17), scaled by 2^m (m <= 0).  v is formed
+// from the EXACT square: n 2 ln2_hi/256 is exact (a 33-bit constant times an integer below 2^19), and one fused
+// multiply-add takes it from z z before that square is ever rounded -- what rounding z^2/2 first would lose
+// (2^-53 of it in the exponent, a relative error of the result that grows with z^2) never arises.  The signs
+// and the factor 1/2 sit in the constants.  Branch-free; underflows gradually to zero.
 __device__ inline double exp_neg_half_square(double z, const double *s) {
-  const double mz = -0.5 * z;
-  const double nf = rint(mz * z * 369.3299304675746);           // 256 / ln 2; z <= 40: fits an int with room
-  double r = fma(mz, z, -(nf * 0.0027076061737716373));         // ln2/256 high part (33 bits: exact product)
-  r = fma(nf, -2.9064910585985925e-13, r);                      // low part
-  const int n = (int)nf;
-  const double t = s[PHI_ROWS * PHI_LD + (n & (EXP_TAB - 1))];
-  double q = fma(r, 1.0 / 24.0, 1.0 / 6.0);
-  q = fma(q, r, 0.5);
-  q = fma(q, r, 1.0);
-  return ldexp(fma(t, q * r, t), n >> 8);
+  const double nf = rint(z * z * 184.6649652337873);             // 128 / ln 2; z <= 40: fits an int with room
+  double v = fma(z, z, -(nf * 0.0054152123475432746));           // 2 ln2/256 high part (33 bits: exact product)
+  v = fma(nf, -5.812982117197185e-13, v);                        // low part
+  const int n = (int)-nf;                                        // -nf = 256 m + j, 0 <= j < 256 (floor division)
+  const double t = s[PHI_ROWS * PHI_LD + (n & (EXP_TAB - 1))];   // 2^(j/256)
+  // (exp(-v/2) - 1) / v = -1/2 + v/8 - v^2/48 + v^3/384
+  double q = fma(v, 1.0 / 384.0, -1.0 / 48.0);
+  q = fma(q, v, 0.125);
+  q = fma(q, v, -0.5);
+  return ldexp(fma(t, q * v, t), n >> 8);
 }
 
 __device__ inline double phi_upper(double z, const double *s) {   // Phi(-z), z >= 0
@@ -56,8 +56,8 @@ __device__ inline double phi_upper(double z, const double *s) {   // Phi(-z), z 
   const double w = z + 1.0;                   // in [1, 41]: exponent 0..5
   const int hi = __double2hiint(w);
   const int k = (hi >> (20 - PHI_S)) - (1023 << PHI_S);          // binade * 64 + top mantissa bits
-  // centre of the interval: the same high word with the lower mantissa bits replaced by 100..0
-  const double t = w - __hiloint2double((hi & ~((1 << (20 - PHI_S)) - 1)) | (1 << (19 - PHI_S)), 0);
+  // lower end of the interval: the same high word with the lower mantissa bits cleared
+  const double t = w - __hiloint2double(hi & ~((1 << (20 - PHI_S)) - 1), 0);
   int row = k * (PHI_LD * 8);
 #ifdef GPIRT_PROBE_SAME_ROW
   row = 100 * (PHI_LD * 8);
