@@ -154,11 +154,15 @@ __device__ inline double unit_sum(double acc, double *red, int w) {
 // (mantissas lie in [1/2, 1)):  sum so far < ln2 * (sum of the lanes' exponents).  Once this
 // integer bound is at or below hh the proposal is rejected whatever the remaining rows hold,
 // and the pass stops there: same decision, most of a far-off proposal's rows never evaluated.
-// Checked every SLICE_CHECK iterations; uniform over the unit's waves.  The waves exchange
+// Checked every SLICE_CHECK iterations (8: with 4 the waves of a unit meet at a barrier every four cells a lane,
+// 1.42 + 1.42 ms for the two updates against 1.39 + 1.34; 16: 1.39 + 1.36); uniform over the unit's waves.  The waves exchange
 // their sums through one of two slots, alternating from check to check: a wave can only write
 // a slot again after the barrier of the check in between, which every wave passes after its
 // reads of that slot.
-constexpr int SLICE_CHECK = 4;
+#ifndef GPIRT_SLICE_CHECK
+#define GPIRT_SLICE_CHECK 8
+#endif
+constexpr int SLICE_CHECK = GPIRT_SLICE_CHECK;
 template <int WPU>
 __device__ inline bool surely_rejected(int e, double hh, int *redi, int w) {
   int v = e;
@@ -207,28 +211,38 @@ __device__ inline double ll_f_pass(const double *__restrict__ f, const double *_
   prod.reset();
   const uint32_t stride = 64 * WPU, last = (uint32_t)(n - 1);
   const int iters = (n + (int)stride - 1) / (int)stride;   // uniform over the unit
-  auto cell = [&](int yy, double fr, double nr, double xr, uint32_t r) {
-    const double gg = (b0 + b1 * xr + b2 * xr * xr) + (fr * c + nr * s);
+  auto cell = [&](int yy, double fr, double nr, double xr, bool live) {
+    const double gg = fma(fma(b2, xr, b1), xr, b0) + (fr * c + nr * s);
     const int yc = max(yy, 1);
     const double p = ordinal_cell_prob(sb[yc - 1] - gg, sb[yc] - gg, sphi);
-    prod.mul(yy > 0 && r <= last ? p : 1.0);
+    prod.mul(yy > 0 && live ? p : 1.0);
   };
   uint32_t r = (uint32_t)row0;
   const uint32_t r0 = min(r, last);
   int ya = col_at(y, r0);
   double fa = col_at(f, r0), na = col_at(nu, r0), xa = col_at(xm, r0);
-  for (int it = 0; it < iters; it += 2, r += 2 * stride) {
+  // trips whose two rows exist for every lane of the unit: no cell is masked by its row number
+  const int whole = n / (int)stride;
+  int it = 0;
+  for (; it + 2 <= whole; it += 2, r += 2 * stride) {
     const uint32_t r1 = min(r + stride, last);
     const int yb = col_at(y, r1);
     const double fb = col_at(f, r1), nb = col_at(nu, r1), xb = col_at(xm, r1);
-    cell(ya, fa, na, xa, r);
+    cell(ya, fa, na, xa, true);
     const uint32_t r2 = min(r + 2 * stride, last);
     ya = col_at(y, r2);
     fa = col_at(f, r2); na = col_at(nu, r2); xa = col_at(xm, r2);
-    cell(yb, fb, nb, xb, r + stride);
+    cell(yb, fb, nb, xb, true);
     if ((it & (SLICE_CHECK - 1)) == SLICE_CHECK - 2 && it + 2 < iters && hh > -INFINITY &&
         surely_rejected<WPU>(prod.e, hh, redi[cp++ & 1], w))
       return -INFINITY;
+  }
+  if (it < iters) {                      // the last trip: rows past the end are masked out
+    const uint32_t r1 = min(r + stride, last);
+    const int yb = col_at(y, r1);
+    const double fb = col_at(f, r1), nb = col_at(nu, r1), xb = col_at(xm, r1);
+    cell(ya, fa, na, xa, r <= last);
+    cell(yb, fb, nb, xb, r + stride <= last);
   }
   return unit_sum<WPU>(prod.log_value(), red, w);
 }
@@ -347,28 +361,37 @@ __device__ inline double ll_param_pass(const double *__restrict__ f, const doubl
   prod.reset();
   const uint32_t stride = 64 * WPU, last = (uint32_t)(n - 1);
   const int iters = (n + (int)stride - 1) / (int)stride;
-  auto cell = [&](int yy, double fr, double xr, uint32_t r) {
-    const double gg = b0 + b1 * xr + b2 * xr * xr + fr;
+  auto cell = [&](int yy, double fr, double xr, bool live) {
+    const double gg = fma(fma(b2, xr, b1), xr, b0) + fr;
     const int yc = max(yy, 1);
     const double p = ordinal_cell_prob(sb[yc - 1] - gg, sb[yc] - gg, sphi);
-    prod.mul(yy > 0 && r <= last ? p : 1.0);
+    prod.mul(yy > 0 && live ? p : 1.0);
   };
   uint32_t r = (uint32_t)row0;
   const uint32_t r0 = min(r, last);
   int ya = col_at(y, r0);
   double fa = col_at(f, r0), xa = col_at(x, r0);
-  for (int it = 0; it < iters; it += 2, r += 2 * stride) {
+  const int whole = n / (int)stride;     // as in ll_f_pass
+  int it = 0;
+  for (; it + 2 <= whole; it += 2, r += 2 * stride) {
     const uint32_t r1 = min(r + stride, last);
     const int yb = col_at(y, r1);
     const double fb = col_at(f, r1), xb = col_at(x, r1);
-    cell(ya, fa, xa, r);
+    cell(ya, fa, xa, true);
     const uint32_t r2 = min(r + 2 * stride, last);
     ya = col_at(y, r2);
     fa = col_at(f, r2); xa = col_at(x, r2);
-    cell(yb, fb, xb, r + stride);
+    cell(yb, fb, xb, true);
     if ((it & (SLICE_CHECK - 1)) == SLICE_CHECK - 2 && it + 2 < iters && hh > -INFINITY &&
         surely_rejected<WPU>(prod.e, hh, redi[cp++ & 1], w))
       return -INFINITY;
+  }
+  if (it < iters) {
+    const uint32_t r1 = min(r + stride, last);
+    const int yb = col_at(y, r1);
+    const double fb = col_at(f, r1), xb = col_at(x, r1);
+    cell(ya, fa, xa, r <= last);
+    cell(yb, fb, xb, r + stride <= last);
   }
   return unit_sum<WPU>(prod.log_value(), red, w);
 }
