@@ -16,6 +16,20 @@ constexpr int WPB = 4;  // waves (units) per workgroup
 
 __device__ inline double bcast0(double v) { return __shfl(v, 0, 64); }
 
+// The cell of response category c (1..C) lies between thresholds c - 1 and c.  The row loops read both
+// ends with one 16-byte load from a table of pairs indexed by the response itself; entry 0, a missing
+// response, is (-inf, +inf), whose cell has probability exactly 1 -- missing responses need no branch
+// and no select.  Called by every lane of a wave with `own` = threshold number `lane` (-inf for lane 0,
+// +inf for lane C); the lower end comes from the lane below by a shuffle (a read of what another lane
+// has just written to LDS needs a fence: to the compiler the two addresses are unrelated).
+__device__ inline void threshold_pairs(double own, double *sb, double2 *sp, int C, int lane) {
+  const double below = __shfl_up(own, 1, 64);
+  if (lane <= C) {
+    sb[lane] = own;
+    sp[lane] = lane == 0 ? make_double2(-INFINITY, INFINITY) : make_double2(below, own);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // plain reductions (parity entry point gpirt_ordinal_loglik, end-of-sweep log-likelihood)
 // ---------------------------------------------------------------------------------------
@@ -204,7 +218,7 @@ __device__ inline int col_at(const int8_t *base, uint32_t r) {
 template <int WPU>
 __device__ inline double ll_f_pass(const double *__restrict__ f, const double *__restrict__ nu,
                                    const double *__restrict__ xm, double b0, double b1, double b2,
-                                   const int8_t *__restrict__ y, const double *sb, const double *sphi,
+                                   const int8_t *__restrict__ y, const double2 *sp, const double *sphi,
                                    int n, int row0, double c, double s, double *red, int w, double hh,
                                    int (*redi)[WPB], int &cp) {
   LogProduct prod;
@@ -213,9 +227,8 @@ __device__ inline double ll_f_pass(const double *__restrict__ f, const double *_
   const int iters = (n + (int)stride - 1) / (int)stride;   // uniform over the unit
   auto cell = [&](int yy, double fr, double nr, double xr, bool live) {
     const double gg = fma(fma(b2, xr, b1), xr, b0) + (fr * c + nr * s);
-    const int yc = max(yy, 1);
-    const double p = ordinal_cell_prob(sb[yc - 1] - gg, sb[yc] - gg, sphi);
-    prod.mul(yy > 0 && live ? p : 1.0);
+    const double2 b = sp[live ? yy : 0];
+    prod.mul(ordinal_cell_prob(b.x - gg, b.y - gg, sphi));
   };
   uint32_t r = (uint32_t)row0;
   const uint32_t r0 = min(r, last);
@@ -250,6 +263,7 @@ __device__ inline double ll_f_pass(const double *__restrict__ f, const double *_
 template <int WPU>
 __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
   __shared__ double sbb[WPB][MAXC + 2];
+  __shared__ __attribute__((aligned(16))) double2 spp[WPB][MAXC + 2];
   __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
   __shared__ double red[WPB];
   __shared__ int redi[2][WPB];
@@ -261,10 +275,13 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
   const int u = WPU == 1 ? __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + w) : blockIdx.x;
   if (u >= a.U_pad || u % a.ML >= a.mloc) return;    // uniform over the workgroup when WPU = 4
   double *sb = sbb[WPU == 1 ? w : 0];
+  double2 *sp = spp[WPU == 1 ? w : 0];
   const int C = a.C, n = a.Np;
   const int row0 = WPU == 1 ? lane : lane + 64 * w;
-  if ((WPU == 1 || w == 0) && lane <= C)
-    sb[lane] = lane == 0 ? -INFINITY : (lane == C ? INFINITY : a.bthr[lane + (int64_t)(C + 1) * u]);
+  if (WPU == 1 || w == 0) {
+    const double own = lane == 0 ? -INFINITY : (lane < C ? a.bthr[lane + (int64_t)(C + 1) * u] : INFINITY);
+    threshold_pairs(own, sb, sp, C, lane);
+  }
   if (WPU != 1) __syncthreads();
   double *f = a.f + a.ld * u;
   const double *nu = a.nu + a.ld * u;
@@ -282,7 +299,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
     return un ? un[d] : rng_uniform_at(a.seed, TAG_F_U, a.sweep, ug, (uint32_t)d);
   };
 
-  const double cur = ll_f_pass<WPU>(f, nu, xm, b0, b1, b2, y, sb, sphi, n, row0, 1.0, 0.0, red, w,
+  const double cur = ll_f_pass<WPU>(f, nu, xm, b0, b1, b2, y, sp, sphi, n, row0, 1.0, 0.0, red, w,
                                     -INFINITY, redi, cp);
   const double hh = log(draw(0)) + cur;              // elliptical_slice.m:66
   double phi = draw(1) * kTwoPi;                     // :72
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
   double l = cur, c = 1.0, s = 0.0;
   while (r < a.R) {
     sincos(phi, &s, &c);
-    l = ll_f_pass<WPU>(f, nu, xm, b0, b1, b2, y, sb, sphi, n, row0, c, s, red, w, hh, redi, cp);  // :85-86
+    l = ll_f_pass<WPU>(f, nu, xm, b0, b1, b2, y, sp, sphi, n, row0, c, s, red, w, hh, redi, cp);  // :85-86
     ++r;
     if (l > hh) { ok = true; break; }                // :87
     if (phi > 0.0) pmax = phi;                       // :92-96
@@ -337,7 +354,7 @@ __device__ inline double lane_value(double v, int k) { return __shfl(v, k, 64); 
 // (beta, thresholds) of the vector `pv`; lanes 0..2 hold the coefficients' prior mean and sd in
 // pm_k, ps_k.  The thresholds accumulate left to right, every lane doing the same additions.
 __device__ inline void params_from_white(double pv, double pm_k, double ps_k, int C, int lane,
-                                         double &b0, double &b1, double &b2, double *sb) {
+                                         double &b0, double &b1, double &b2, double *sb, double2 *sp) {
   const double bk = pm_k + ps_k * pv;
   b0 = lane_value(bk, 0);
   b1 = lane_value(bk, 1);
@@ -348,13 +365,13 @@ __device__ inline void params_from_white(double pv, double pm_k, double ps_k, in
     acc += lane_value(ek, c + 2);
     if (lane == c) mine = acc;
   }
-  if (lane <= C) sb[lane] = lane == 0 ? -INFINITY : (lane == C ? INFINITY : mine);
+  threshold_pairs(lane == 0 ? -INFINITY : (lane < C ? mine : INFINITY), sb, sp, C, lane);
 }
 
 template <int WPU>
 __device__ inline double ll_param_pass(const double *__restrict__ f, const double *__restrict__ x,
                                        double b0, double b1, double b2,
-                                       const int8_t *__restrict__ y, const double *sb,
+                                       const int8_t *__restrict__ y, const double2 *sp,
                                        const double *sphi, int n, int row0, double *red, int w,
                                        double hh, int (*redi)[WPB], int &cp) {
   LogProduct prod;                       // pipelined like ll_f_pass, same early rejection
@@ -363,9 +380,8 @@ __device__ inline double ll_param_pass(const double *__restrict__ f, const doubl
   const int iters = (n + (int)stride - 1) / (int)stride;
   auto cell = [&](int yy, double fr, double xr, bool live) {
     const double gg = fma(fma(b2, xr, b1), xr, b0) + fr;
-    const int yc = max(yy, 1);
-    const double p = ordinal_cell_prob(sb[yc - 1] - gg, sb[yc] - gg, sphi);
-    prod.mul(yy > 0 && live ? p : 1.0);
+    const double2 b = sp[live ? yy : 0];
+    prod.mul(ordinal_cell_prob(b.x - gg, b.y - gg, sphi));
   };
   uint32_t r = (uint32_t)row0;
   const uint32_t r0 = min(r, last);
@@ -399,6 +415,7 @@ __device__ inline double ll_param_pass(const double *__restrict__ f, const doubl
 template <int WPU>
 __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
   __shared__ double sbb[WPB][MAXC + 2];
+  __shared__ __attribute__((aligned(16))) double2 spp[WPB][MAXC + 2];
   __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
   __shared__ double red[WPB];
   __shared__ int redi[2][WPB];
@@ -409,6 +426,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
   const int u = WPU == 1 ? __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + w) : blockIdx.x;
   if (u >= a.U_pad || u % a.ML >= a.mloc) return;    // uniform over the workgroup when WPU = 4
   double *sb = sbb[WPU == 1 ? w : 0];
+  double2 *sp = spp[WPU == 1 ? w : 0];
   const int row0 = WPU == 1 ? lane : lane + 64 * w;
   const int C = a.C, n = a.Np, D = C + 2, jl = u % a.ML;
   const double *f = a.f + a.ld * u;
@@ -430,11 +448,11 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
   double pv = v;
 
   double b0, b1, b2;
-  params_from_white(v, pm_k, ps_k, C, lane, b0, b1, b2, sb);
+  params_from_white(v, pm_k, ps_k, C, lane, b0, b1, b2, sb, sp);
   if (WPU != 1) __syncthreads();          // the thresholds every wave just wrote (same values)
   // the slice update of f that ran just before left the log-likelihood of exactly this state
   const double cur = a.ll_in ? a.ll_in[u]
-                             : ll_param_pass<WPU>(f, x, b0, b1, b2, y, sb, sphi, n, row0, red, w, -INFINITY, redi, cp);
+                             : ll_param_pass<WPU>(f, x, b0, b1, b2, y, sp, sphi, n, row0, red, w, -INFINITY, redi, cp);
   int r = 0;
   bool ok = false;
   double l = cur;
@@ -447,9 +465,9 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
       sincos(phi, &s, &c);
       pv = rotates ? v * c + nv * s : v;
       // (every wave has left the last pass: its final sum, or the check that ended it, is a barrier)
-      params_from_white(pv, pm_k, ps_k, C, lane, b0, b1, b2, sb);
+      params_from_white(pv, pm_k, ps_k, C, lane, b0, b1, b2, sb, sp);
       if (WPU != 1) __syncthreads();
-      l = ll_param_pass<WPU>(f, x, b0, b1, b2, y, sb, sphi, n, row0, red, w, hh, redi, cp);
+      l = ll_param_pass<WPU>(f, x, b0, b1, b2, y, sp, sphi, n, row0, red, w, hh, redi, cp);
       ++r;
       if (l > hh) { ok = true; break; }
       if (phi > 0.0) pmax = phi;
@@ -459,7 +477,7 @@ __global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
     }
   }
   if (!ok) {  // keep the current parameters
-    params_from_white(v, pm_k, ps_k, C, lane, b0, b1, b2, sb);
+    params_from_white(v, pm_k, ps_k, C, lane, b0, b1, b2, sb, sp);
     l = cur;
   }
   if (WPU != 1) __syncthreads();
