@@ -18,4 +18,8 @@ cp gpurun_out/$tag/pmc_kernels.json profiles/$(python3 -c "import bench; print(b
 bash tools/profile_round.sh gpurun_out/$tag/full || exit 1
 BENCH_ARGS="--m 1024" bash tools/kstats.sh gpurun_out/$tag/m1024 > gpurun_out/$tag/m1024.txt || exit 1
 BENCH_ARGS="--m 512" bash tools/kstats.sh gpurun_out/$tag/m512 > gpurun_out/$tag/m512.txt || exit 1
+# the bench line itself at a rank's share of the items (2048 / 1024 / 512: two, four, eight ranks)
+for M in 2048 1024 512; do
+  timeout -k 10 300 python -u bench.py --steps 20 --warmup 3 --m $M --no-cpu-baseline --no-variants > gpurun_out/$tag/items$M.json 2> gpurun_out/$tag/items$M.err || { tail -5 gpurun_out/$tag/items$M.err; exit 1; }
+done
 echo done
