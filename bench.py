@@ -481,7 +481,11 @@ def main():
                         "flop_per_launch": fl_launch, "ms_per_launch": nu_ms,
                         "algorithmic_bytes_per_launch": 8.0 * ((float(n) * n - float(r0) * r0) / 2 - float(k0) * (n - r0)
                                                                + float(n - k0) * mloc + (2.0 if k0 else 1.0) * (n - r0) * mloc),
-                        "traffic": nu_pmc["hbm_bytes_per_launch"] if nu_pmc else None},
+                        "traffic": nu_pmc["hbm_bytes_per_launch"] if nu_pmc else None,
+                        "note": ("this launch shares the chip with the chunk of rows that the second stream has not "
+                                 "finished when the factorisation ends (224 workgroups on 224 CUs for about half of "
+                                 "the launch's span in the kernel trace): `achieved` counts this launch's flop only, "
+                                 "the two together run at ~0.8 of peak over the span (DESIGN.md, section 3)") if r0 > 0 else None},
                 },
             },
             "substeps": substeps(n, mloc, C, cfg.n_grid, phases, evals, r0, lookahead, k0),
