@@ -261,7 +261,11 @@ constexpr int BUCKET_CHUNK_MAX = 1024;   // items per chunk: at most 16 per lane
 
 __global__ __launch_bounds__(256) void theta_eval_bucket_kernel(ThetaArgs a) {
   extern __shared__ double rows[];                        // [C][chunk]
-  const int g = blockIdx.x, ch = blockIdx.y;
+  // Buckets are dealt out from the middle of the grid outwards: respondents crowd around the centre of
+  // the prior, and the workgroups of the fullest buckets, which set the launch's length, start first.
+  const int mid = a.G / 2, bx = blockIdx.x;
+  const int g = (bx & 1) ? mid - (bx + 1) / 2 : (mid + bx / 2 < a.G ? mid + bx / 2 : a.G - 1 - bx);
+  const int ch = blockIdx.y;
   const int b0 = a.bstart[g], b1 = a.bstart[g + 1];
   if (b0 >= b1) return;                                   // uniform over the workgroup
   const int chunk = a.chunk, C = a.C, j0 = ch * chunk, cnt = min(chunk, a.mloc - j0);
@@ -277,10 +281,14 @@ __global__ __launch_bounds__(256) void theta_eval_bucket_kernel(ThetaArgs a) {
     constexpr int LOADS = 6144 / 256;                     // C * chunk <= 6144
     double tmp[LOADS];
     const int total = C * chunk;
+    // (category, item) of entry e = thread + 256 q without a division per entry: the chunk is at least 64 wide
+    int c = threadIdx.x / chunk, k = threadIdx.x - c * chunk;
 #pragma unroll
     for (int q = 0; q < LOADS; ++q) {
-      const int e = threadIdx.x + 256 * q, c = e / chunk, k = e - c * chunk;
+      const int e = threadIdx.x + 256 * q;
       tmp[q] = (e < total && k < cnt) ? src[U_pad * c + k] : 0.0;
+      k += 256;
+      while (k >= chunk) { k -= chunk; ++c; }
     }
 #pragma unroll
     for (int q = 0; q < LOADS; ++q) {
