@@ -13,6 +13,9 @@
 namespace gpirt {
 
 constexpr int WPB = 4;  // waves (units) per workgroup
+constexpr int WMAX = 8; // most waves a unit can have
+// waves of a workgroup whose units have WPU waves each
+constexpr int block_waves(int WPU) { return WPU > WPB ? WPU : WPB; }
 
 __device__ inline double bcast0(double v) { return __shfl(v, 0, 64); }
 
@@ -159,7 +162,9 @@ __device__ inline double unit_sum(double acc, double *red, int w) {
   __syncthreads();                       // everyone is done with the previous sums
   if ((threadIdx.x & 63) == 0) red[w] = v;
   __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);   // fixed order: identical in every wave
+  const double lo4 = (red[0] + red[1]) + (red[2] + red[3]);   // fixed order: identical in every wave
+  if (WPU == 4) return lo4;
+  return lo4 + ((red[4] + red[5]) + (red[6] + red[7]));
 }
 
 // A proposal is accepted when its log-likelihood exceeds the slice height hh
@@ -186,6 +191,7 @@ __device__ inline bool surely_rejected(int e, double hh, int *redi, int w) {
     if ((threadIdx.x & 63) == 0) redi[w] = v;
     __syncthreads();
     v = (redi[0] + redi[1]) + (redi[2] + redi[3]);
+    if (WPU == 8) v += (redi[4] + redi[5]) + (redi[6] + redi[7]);
   }
   return (double)v * 0.69314718055994530942 <= hh;
 }
@@ -220,7 +226,7 @@ __device__ inline double ll_f_pass(const double *__restrict__ f, const double *_
                                    const double *__restrict__ xm, double b0, double b1, double b2,
                                    const int8_t *__restrict__ y, const double2 *sp, const double *sphi,
                                    int n, int row0, double c, double s, double *red, int w, double hh,
-                                   int (*redi)[WPB], int &cp) {
+                                   int (*redi)[WMAX], int &cp) {
   LogProduct prod;
   prod.reset();
   const uint32_t stride = 64 * WPU, last = (uint32_t)(n - 1);
@@ -261,12 +267,12 @@ __device__ inline double ll_f_pass(const double *__restrict__ f, const double *_
 }
 
 template <int WPU>
-__global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
+__global__ __launch_bounds__(64 * block_waves(WPU)) void ess_f_kernel(EssFArgs a) {
   __shared__ double sbb[WPB][MAXC + 2];
   __shared__ __attribute__((aligned(16))) double2 spp[WPB][MAXC + 2];
   __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
-  __shared__ double red[WPB];
-  __shared__ int redi[2][WPB];
+  __shared__ double red[WMAX];
+  __shared__ int redi[2][WMAX];
   phi_table_to_lds(sphi);
   __syncthreads();
   int cp = 0;   // checks so far: consecutive checks alternate between the two exchange slots
@@ -333,7 +339,13 @@ __global__ __launch_bounds__(64 * WPB) void ess_f_kernel(EssFArgs a) {
 constexpr int WIDE_UNIT_ROWS = 1024;
 
 int launch_ess_f(hipStream_t st, const EssFArgs &a) {
-  if (a.Np >= WIDE_UNIT_ROWS)
+  // Eight waves (EssFArgs::wide8, the caller's choice: it changes the order of a unit's sums): with few units
+  // the launch is as long as its longest unit, and a wave that has its SIMD to itself issues at half the rate of
+  // two -- n = 10 000: 512 units 0.37 -> 0.30 ms, 1024 units 0.48 -> 0.46, 2048 and more: no shorter.  (The
+  // parameter update needs 151 registers: eight-wave workgroups then fit one to a CU, and it is slower at every size.)
+  if (a.wide8 && a.Np >= WIDE_UNIT_ROWS)
+    hipLaunchKernelGGL(ess_f_kernel<8>, dim3(a.U_pad), dim3(64 * 8), 0, st, a);
+  else if (a.Np >= WIDE_UNIT_ROWS)
     hipLaunchKernelGGL(ess_f_kernel<4>, dim3(a.U_pad), dim3(64 * WPB), 0, st, a);
   else
     hipLaunchKernelGGL(ess_f_kernel<1>, dim3((a.U_pad + WPB - 1) / WPB), dim3(64 * WPB), 0, st, a);
@@ -373,7 +385,7 @@ __device__ inline double ll_param_pass(const double *__restrict__ f, const doubl
                                        double b0, double b1, double b2,
                                        const int8_t *__restrict__ y, const double2 *sp,
                                        const double *sphi, int n, int row0, double *red, int w,
-                                       double hh, int (*redi)[WPB], int &cp) {
+                                       double hh, int (*redi)[WMAX], int &cp) {
   LogProduct prod;                       // pipelined like ll_f_pass, same early rejection
   prod.reset();
   const uint32_t stride = 64 * WPU, last = (uint32_t)(n - 1);
@@ -413,12 +425,12 @@ __device__ inline double ll_param_pass(const double *__restrict__ f, const doubl
 }
 
 template <int WPU>
-__global__ __launch_bounds__(64 * WPB) void ess_param_kernel(EssParamArgs a) {
+__global__ __launch_bounds__(64 * block_waves(WPU)) void ess_param_kernel(EssParamArgs a) {
   __shared__ double sbb[WPB][MAXC + 2];
   __shared__ __attribute__((aligned(16))) double2 spp[WPB][MAXC + 2];
   __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
-  __shared__ double red[WPB];
-  __shared__ int redi[2][WPB];
+  __shared__ double red[WMAX];
+  __shared__ int redi[2][WMAX];
   phi_table_to_lds(sphi);
   __syncthreads();
   int cp = 0;   // checks so far: consecutive checks alternate between the two exchange slots

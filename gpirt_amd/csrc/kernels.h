@@ -29,6 +29,7 @@ struct EssFArgs {
   uint64_t seed; uint32_t sweep;
   int32_t *rounds; double *ll;               // per-unit outputs (optional)
   unsigned long long *counters;              // [0] likelihood evaluations, [1] capped updates
+  int wide8;                                 // eight waves per unit instead of four (few units of many rows)
 };
 int launch_ess_f(hipStream_t st, const EssFArgs &a);
 

@@ -1196,6 +1196,9 @@ static int phase_f(gpirt_sampler *s) {
   a.Np = s->Np; a.U_pad = s->U_pad; a.C = s->C; a.mloc = s->mloc; a.ML = s->ML; a.m = s->m;
   a.j0 = s->j0; a.R = s->cfg.max_ess_rounds; a.seed = s->seed; a.sweep = s->sweep;
   a.rounds = nullptr; a.ll = s->d_llu; a.counters = s->d_counters;
+  // few units of many rows: eight waves a unit.  Not under GPIRT_FIXED_ORDER_SUM, whose promise -- the same bits for
+  // every number of ranks -- would not survive an order of summation that depends on a rank's share of the units
+  a.wide8 = s->Np >= 4096 && s->mloc * s->P <= 1536 && !(s->cfg.flags & GPIRT_FIXED_ORDER_SUM);
   GP_TRY(launch_ess_f(s->st, a));
   return GPIRT_OK;
 }
