@@ -1297,7 +1297,12 @@ static int phase_fstar(gpirt_sampler *s) {
     if (s->P == 1 && tiles < 512 && s->Np_pad >= 2048) {
       const int slabs = s->Np_pad / 16;
       const int64_t room = ((int64_t)s->Np_pad * s->U_pad) / ((int64_t)s->ML * R);
-      for (int q = 2; q <= 16 && q <= room && tiles * q <= 1024; ++q)
+      // With a rank's share of the items there are only a few output tiles, and eight slabs of K leave each
+      // workgroup more than a thousand steps deep on a mostly empty chip (n = 10 000, 512 items: 32 workgroups,
+      // 176 us); as many slabs as there are 128-deep blocks of K fill it (316 workgroups, 25 us + 11 us of summing).
+      // Under GPIRT_FIXED_ORDER_SUM the slabs stay what every number of ranks would choose.
+      const int most = (s->cfg.flags & GPIRT_FIXED_ORDER_SUM) ? 16 : 128;
+      for (int q = 2; q <= most && q <= room && tiles * q <= 1024 && s->Np_pad / q >= TILE; ++q)
         if (slabs % q == 0) splits = q;
     }
     if (splits > 1) {   // few output tiles, long K: partial products parked in Z, then summed
