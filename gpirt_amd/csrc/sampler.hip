@@ -1463,8 +1463,8 @@ static int phase_theta(gpirt_sampler *s) {
   bool finished = false;
   while (r <= max_rounds && !finished) {
     // a round nobody needs any more costs three kernels that return at once, less than a look (~35 us of idle
-    // GPU): the first four rounds go out together -- hardly a sweep needs fewer -- then two at a time
-    const int last = sharded ? r : min(max_rounds, r < 2 ? 4 : r + 1);
+    // GPU): the first four rounds go out together -- hardly a sweep needs fewer -- then three at a time
+    const int last = sharded ? r : min(max_rounds, r < 2 ? 4 : r + 2);
     const bool wide = many_items || active * 4 <= s->n;
     for (int q = r; q <= last; ++q) {
       GP_TRY(eval(0, wide));
