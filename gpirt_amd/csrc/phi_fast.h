@@ -93,7 +93,7 @@ __device__ inline double ordinal_cell_prob(double zlo, double zhi, const double 
 }
 
 __device__ inline double ordinal_cell_fast(double zlo, double zhi, const double *s) {
-  return log(ordinal_cell_prob(zlo, zhi, s));
+  return log_pos(ordinal_cell_prob(zlo, zhi, s), kLogTab);
 }
 
 // Sum of log-probabilities as the log of their product: the running product is kept as
@@ -110,7 +110,7 @@ struct LogProduct {
     m = __builtin_amdgcn_frexp_mant(q);
     e += __builtin_amdgcn_frexp_exp(q);
   }
-  __device__ inline double log_value() const { return log(m) + (double)e * 0.69314718055994530942; }
+  __device__ inline double log_value() const { return log_pos(m, kLogTab) + (double)e * 0.69314718055994530942; }
 };
 
 }  // namespace gpirt

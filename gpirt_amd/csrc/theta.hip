@@ -127,7 +127,9 @@ __global__ __launch_bounds__(256) void theta_eval_kernel(ThetaArgs a, int initia
 // round) and a likelihood evaluation becomes a sum of gathered table entries.
 __global__ __launch_bounds__(256) void theta_table_kernel(ThetaArgs a) {
   __shared__ __attribute__((aligned(16))) double sphi[PHI_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double slog[LOG_LDS_DOUBLES];
   phi_table_to_lds(sphi);
+  log_table_to_lds(slog);
   __syncthreads();
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   const int U_pad = a.U_pad, C = a.C;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void theta_table_kernel(ThetaArgs a) {
     for (int c = 0; c < C; ++c) {
       const double zhi = c + 1 < C ? fmin(fmax(a.bthrS[u + (int64_t)U_pad * (c + 1)] - F, -1e30), 1e30) : 1e30;
       const double e2 = phi_upper(fabs(zhi), sphi);
-      out[(int64_t)U_pad * c] = log(ordinal_cell_from_tails(zlo, zhi, e1, e2));
+      out[(int64_t)U_pad * c] = log_pos(ordinal_cell_from_tails(zlo, zhi, e1, e2), slog);
       zlo = zhi; e1 = e2;
     }
   }
