@@ -67,6 +67,7 @@ struct ThetaArgs {
   const double *Gt;         // [U_pad, G_pad] f* with the unit index contiguous
   const double *betaS, *bthrS;
   const int8_t *yT;         // [ML*H, n] responses, respondent-major
+  const int8_t *yTl;        // the same with the items of a chunk lane-major (theta_lane_major), or nullptr
   double *tab;              // [U_pad, C, G] log cell probabilities on the grid (table variant) or null
   // bucketed evaluation of the table variant (H = 1): respondents grouped by grid index
   int32_t *gidx, *order;    // [SPEC*n] grid index of the evaluated theta (-1: none), entries by bucket
@@ -106,6 +107,8 @@ int launch_theta_table(hipStream_t st, const ThetaArgs &a);
 constexpr int THETA_BUCKET_MAX_G = 2048;
 int theta_bucket_chunk(int C);
 int launch_theta_eval_bucketed(hipStream_t st, const ThetaArgs &a, int initial);
+// yTl[i][ch*chunk + lane*(chunk/64) + t] = yT[i][ch*chunk + lane + 64 t]; chunk must be 512 or 1024
+int launch_theta_lane_major(hipStream_t st, const int8_t *yT, int n, int ML, int chunk, int8_t *yTl);
 // q0 = 0: set the slice height from the current state's log-likelihood and draw proposals
 // 1..SPEC; q0 > 0: the round evaluated proposals q0..q0+SPEC-1.  round = index into remaining.
 int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int q0, int round);

@@ -127,7 +127,7 @@ struct gpirt_sampler {
   uint32_t sweep;
   double jitter_now;
   hipStream_t st;
-  int8_t *d_y, *d_yT;
+  int8_t *d_y, *d_yT, *d_yTl = nullptr;   // yTl: yT with a chunk's items lane-major (bucketed respondent step)
   double *d_theta, *d_f, *d_Z, *d_nu, *d_S, *d_inv, *d_fwork, *d_xtmp, *d_W, *d_Gt;
   double *d_ebeta, *d_delta, *d_beta, *d_bthr, *d_betaS, *d_bthrS, *d_bpm, *d_bps;
   double *d_xc, *d_tnu, *d_prop, *d_hh, *d_phi, *d_pmin, *d_pmax, *d_buf, *d_Lt, *d_tpm, *d_tps;
@@ -208,7 +208,7 @@ struct gpirt_sampler {
 
 static void sampler_free(gpirt_sampler *s) {
   if (!s) return;
-  void *ptrs[] = {s->d_y, s->d_yT, s->d_theta, s->d_f, s->d_Z, s->d_nu, s->d_S, s->d_inv, s->d_fwork, s->d_xtmp, s->d_W,
+  void *ptrs[] = {s->d_y, s->d_yT, s->d_yTl, s->d_theta, s->d_f, s->d_Z, s->d_nu, s->d_S, s->d_inv, s->d_fwork, s->d_xtmp, s->d_W,
                   s->d_Gt, s->d_ebeta, s->d_delta, s->d_beta, s->d_bthr, s->d_betaS, s->d_bthrS,
                   s->d_bpm, s->d_bps, s->d_xc, s->d_tnu, s->d_prop, s->d_hh, s->d_phi, s->d_pmin,
                   s->d_pmax, s->d_buf, s->d_Lt, s->d_tpm, s->d_tps, s->d_llu, s->d_done, s->d_info,
@@ -729,6 +729,8 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
       s->th_nslots = fixed ? (s->m + s->th_chunk - 1) / s->th_chunk : s->th_nchunks;
       A_(s->d_part, (size_t)s->th_nslots * THETA_SPEC * n);
       A_(s->d_gidx, (size_t)THETA_SPEC * n); A_(s->d_order, (size_t)THETA_SPEC * n); A_(s->d_bstart, (size_t)s->G + 1); A_(s->d_ghist, s->G);
+      // the wide chunks read the responses from a lane-major copy (whole chunks only: ML is a multiple of 128)
+      if ((s->th_chunk == 512 || s->th_chunk == 1024) && ML % s->th_chunk == 0) A_(s->d_yTl, (size_t)ML * n);
     }
   }
 #undef A_
@@ -797,6 +799,10 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     if ((rc = setup_fstar_interpolation(s))) return fail(rc);
     if (!(cfg->flags & GPIRT_FSTAR_SOLVE) && (rc = setup_fstar_lowrank(s))) return fail(rc);
     if ((cfg->flags & GPIRT_GENERATOR_PRIOR) && (rc = setup_generator_prior(s))) return fail(rc);
+  }
+  if (s->d_yTl) {
+    if ((rc = launch_theta_lane_major(s->st, s->d_yT, n, ML, s->th_chunk, s->d_yTl))) return fail(rc);
+    if (hipStreamSynchronize(s->st) != hipSuccess) { set_error("lane-major copy of the responses failed"); return fail(GPIRT_ERR_HIP); }
   }
   if (cfg->theta_mode == GPIRT_THETA_GRID) {
     if ((rc = launch_grid_onehot(s->st, s->d_yT, n, mloc, ML, C, s->d_onehot))) return fail(rc);
@@ -1381,7 +1387,7 @@ static ThetaArgs theta_args(gpirt_sampler *s) {
   a.theta = s->d_theta; a.xc = s->d_xc; a.nu = s->d_tnu; a.prop = s->d_prop; a.hh = s->d_hh;
   a.phi = s->d_phi; a.pmin = s->d_pmin; a.pmax = s->d_pmax; a.done = s->d_done; a.buf = s->d_buf;
   a.Lt = s->d_Lt; a.tpm = s->d_tpm; a.tps = s->d_tps; a.Gt = s->d_Gt; a.betaS = s->d_betaS;
-  a.bthrS = s->d_bthrS; a.yT = s->d_yT; a.n = s->n; a.H = s->H; a.C = s->C; a.mloc = s->mloc;
+  a.bthrS = s->d_bthrS; a.yT = s->d_yT; a.yTl = s->d_yTl; a.n = s->n; a.H = s->H; a.C = s->C; a.mloc = s->mloc;
   a.ML = s->ML; a.U_pad = s->U_pad; a.G = s->G; a.constant_irf = s->cfg.constant_irf;
   a.R = s->cfg.max_ess_rounds; a.grid_lo = s->cfg.grid_lo; a.grid_step = s->cfg.grid_step;
   a.index_truncate = (s->cfg.flags & GPIRT_INDEX_TRUNCATE) ? 1 : 0;

@@ -7,6 +7,7 @@
 // the ordinal-probit cell of log_like_fn.m:3-4 / gpirt-sythetic.R:159-167 is summed over
 // this rank's items.  All respondents advance in lock-step rounds so that, when items are
 // sharded over GPUs, one n-vector sum-all-reduce per round is the only exchange.
+#include <type_traits>
 #include "kernels.h"
 #include "phi_fast.h"
 
@@ -326,6 +327,85 @@ __global__ __launch_bounds__(256) void theta_eval_bucket_kernel(ThetaArgs a) {
   }
 }
 
+// The same evaluation for chunks of 512 or 1024 items, with the responses read from a copy in which the items a
+// lane serves (lane, lane + 64, ...) lie side by side: one 8- or 16-byte load per respondent and lane instead of
+// 8 or 16 byte loads with their address arithmetic.  The table rows sit behind a row of zeros, so that a response
+// indexes its row directly and a missing one (0) adds zero: no select.  Same sums in the same order.
+template <int PERC>
+__global__ __launch_bounds__(256) void theta_eval_bucket_lane_kernel(ThetaArgs a) {
+  extern __shared__ double rows[];                        // [C + 1][chunk], row 0 zero
+  const int mid = a.G / 2, bx = blockIdx.x;
+  const int g = (bx & 1) ? mid - (bx + 1) / 2 : (mid + bx / 2 < a.G ? mid + bx / 2 : a.G - 1 - bx);
+  const int ch = blockIdx.y;
+  const int b0 = a.bstart[g], b1 = a.bstart[g + 1];
+  if (b0 >= b1) return;                                   // uniform over the workgroup
+  constexpr int chunk = 64 * PERC, STEP = 4;
+  const int C = a.C, j0 = ch * chunk, cnt = min(chunk, a.mloc - j0);
+  const int64_t U_pad = a.U_pad;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  using word_t = typename std::conditional<PERC == 16, uint4, uint2>::type;
+  auto load_y = [&](int i) -> word_t {
+    return *reinterpret_cast<const word_t *>(a.yTl + (int64_t)a.ML * (i % a.n) + j0 + lane * PERC);
+  };
+  int r = b0 + w;
+  int i0 = a.order[min(r, b1 - 1)], i1 = a.order[min(r + STEP, b1 - 1)];
+  {  // stage the rows: all loads of a thread are issued before the first store
+    const double *src = a.tab + U_pad * C * g + j0;
+    constexpr int LOADS = 6144 / 256;                     // C * chunk <= 6144
+    double tmp[LOADS];
+    const int total = C * chunk;
+    int c = threadIdx.x / chunk, k = threadIdx.x - c * chunk;
+#pragma unroll
+    for (int q = 0; q < LOADS; ++q) {
+      const int e = threadIdx.x + 256 * q;
+      tmp[q] = (e < total && k < cnt) ? src[U_pad * c + k] : 0.0;
+      k += 256;
+      while (k >= chunk) { k -= chunk; ++c; }
+    }
+    for (int e = threadIdx.x; e < chunk; e += 256) rows[e] = 0.0;
+#pragma unroll
+    for (int q = 0; q < LOADS; ++q) {
+      const int e = threadIdx.x + 256 * q;
+      if (e < total) rows[chunk + e] = tmp[q];
+    }
+  }
+  word_t yv = load_y(i0);
+  __syncthreads();
+  const double *mine = rows + lane;
+  for (; r < b1; r += STEP) {
+    const int i2 = a.order[min(r + 2 * STEP, b1 - 1)];
+    const word_t yn = load_y(i1);
+    uint32_t wd[4] = {yv.x, yv.y, 0u, 0u};
+    if constexpr (PERC == 16) { wd[2] = yv.z; wd[3] = yv.w; }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int t = 0; t < PERC; t += 2) {
+      const uint32_t ya = (wd[t >> 2] >> (8 * (t & 3))) & 0xFFu, yb = (wd[(t + 1) >> 2] >> (8 * ((t + 1) & 3))) & 0xFFu;
+      s0 += mine[ya * chunk + 64 * t];
+      s1 += mine[yb * chunk + 64 * (t + 1)];
+    }
+    const double acc = wave_sum(s0 + s1);
+    if (lane == 0) a.part[(int64_t)(a.slot0 + ch) * THETA_SPEC * a.n + i0] = acc;
+    yv = yn;
+    i0 = i1; i1 = i2;
+  }
+}
+
+__global__ void theta_lane_major_kernel(const int8_t *__restrict__ yT, int n, int ML, int chunk, int8_t *__restrict__ yTl) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (pos >= ML || i >= n) return;
+  const int perc = chunk / 64, ch = pos / chunk, wi = pos - ch * chunk, lane = wi / perc, t = wi - lane * perc;
+  const int src = ch * chunk + lane + 64 * t;
+  yTl[(int64_t)ML * i + pos] = src < ML ? yT[(int64_t)ML * i + src] : (int8_t)0;
+}
+
+int launch_theta_lane_major(hipStream_t st, const int8_t *yT, int n, int ML, int chunk, int8_t *yTl) {
+  if (chunk != 512 && chunk != 1024) return GPIRT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(theta_lane_major_kernel, dim3((ML + 255) / 256, n), dim3(256), 0, st, yT, n, ML, chunk, yTl);
+  GP_HIP(hipGetLastError());
+  return GPIRT_OK;
+}
+
 __global__ void theta_sum_chunks_kernel(ThetaArgs a, int count) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= count) return;
@@ -344,8 +424,14 @@ int launch_theta_eval_bucketed(hipStream_t st, const ThetaArgs &a, int initial) 
   const int count = initial ? a.n : THETA_SPEC * a.n;
   hipLaunchKernelGGL(theta_bucket_kernel, dim3(1), dim3(1024), 0, st, a, count);
   GP_HIP(hipGetLastError());
-  hipLaunchKernelGGL(theta_eval_bucket_kernel, dim3(a.G, a.nchunks), dim3(256),
-                     sizeof(double) * (size_t)a.C * a.chunk, st, a);
+  const size_t lane_lds = sizeof(double) * (size_t)(a.C + 1) * a.chunk;
+  if (a.yTl && a.chunk == 1024 && a.ML % 1024 == 0)
+    hipLaunchKernelGGL(theta_eval_bucket_lane_kernel<16>, dim3(a.G, a.nchunks), dim3(256), lane_lds, st, a);
+  else if (a.yTl && a.chunk == 512 && a.ML % 512 == 0)
+    hipLaunchKernelGGL(theta_eval_bucket_lane_kernel<8>, dim3(a.G, a.nchunks), dim3(256), lane_lds, st, a);
+  else
+    hipLaunchKernelGGL(theta_eval_bucket_kernel, dim3(a.G, a.nchunks), dim3(256),
+                       sizeof(double) * (size_t)a.C * a.chunk, st, a);
   GP_HIP(hipGetLastError());
   if (!a.from_parts) {     // someone other than the decision kernel needs the sums (the exchange)
     hipLaunchKernelGGL(theta_sum_chunks_kernel, dim3((count + 255) / 256), dim3(256), 0, st, a, count);
