@@ -72,6 +72,7 @@ struct ThetaArgs {
   // bucketed evaluation of the table variant (H = 1): respondents grouped by grid index
   int32_t *gidx, *order;    // [SPEC*n] grid index of the evaluated theta (-1: none), entries by bucket
   int32_t *bstart;          // [G+1] bucket g holds order[bstart[g] .. bstart[g+1])
+  int32_t *bcur;            // [G] next free place of bucket g while the entries are being filed
   int32_t *ghist;           // [G] respondents per grid index, counted by the prepare / decision kernels
   double *part;             // [nslots, SPEC*n] partial sums per item chunk
   int chunk, nchunks;       // items per chunk (multiple of 64), number of this rank's chunks

@@ -137,7 +137,7 @@ struct gpirt_sampler {
   double *d_nuparts;               // partial products of nu = L Z when K is split (else null)
   int nu_splits;
   double *d_part;                  // bucketed evaluation of the table variant (H = 1, else null)
-  int32_t *d_gidx, *d_order, *d_bstart, *d_ghist;
+  int32_t *d_gidx, *d_order, *d_bstart, *d_bcur, *d_ghist;
   int th_chunk, th_nchunks;
   int th_slot0, th_nslots;         // GPIRT_FIXED_ORDER_SUM: this rank's first block among all ranks' blocks
   double *d_sum_th, *d_sum_th2, *d_sum_p, *d_sum_arg;   // running sums of the summaries (lazy)
@@ -214,7 +214,7 @@ static void sampler_free(gpirt_sampler *s) {
                   s->d_pmax, s->d_buf, s->d_Lt, s->d_tpm, s->d_tps, s->d_llu, s->d_done, s->d_info,
                   s->d_counters, s->d_onehot, s->d_T, s->d_lp,
                   s->d_sum_th, s->d_sum_th2, s->d_sum_p, s->d_sum_arg, s->d_nodes, s->d_lag, s->d_tab,
-                  s->d_part, s->d_gidx, s->d_order, s->d_bstart, s->d_ghist, s->d_nuparts,
+                  s->d_part, s->d_gidx, s->d_order, s->d_bstart, s->d_bcur, s->d_ghist, s->d_nuparts,
                   s->d_bw, s->d_B, s->d_BL, s->d_feat, s->d_Mm, s->d_minv, s->d_X, s->d_gparts,
                   s->d_Jb, s->d_jinv, s->d_Tb, s->d_Sbb, s->d_linv, s->d_Et, s->d_Wt, s->d_V};
   for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -728,7 +728,7 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
       s->th_slot0 = fixed ? s->j0 / s->th_chunk : 0;
       s->th_nslots = fixed ? (s->m + s->th_chunk - 1) / s->th_chunk : s->th_nchunks;
       A_(s->d_part, (size_t)s->th_nslots * THETA_SPEC * n);
-      A_(s->d_gidx, (size_t)THETA_SPEC * n); A_(s->d_order, (size_t)THETA_SPEC * n); A_(s->d_bstart, (size_t)s->G + 1); A_(s->d_ghist, s->G);
+      A_(s->d_gidx, (size_t)THETA_SPEC * n); A_(s->d_order, (size_t)THETA_SPEC * n); A_(s->d_bstart, (size_t)s->G + 1); A_(s->d_bcur, s->G); A_(s->d_ghist, s->G);
       // the wide chunks read the responses from a lane-major copy (whole chunks only: ML is a multiple of 128)
       if ((s->th_chunk == 512 || s->th_chunk == 1024) && ML % s->th_chunk == 0) A_(s->d_yTl, (size_t)ML * n);
     }
@@ -1395,7 +1395,7 @@ static ThetaArgs theta_args(gpirt_sampler *s) {
   a.counters = s->d_counters + 4;
   a.ll_seen = (s->cfg.flags & GPIRT_FIXED_ORDER_SUM) ? s->d_counters + 6 : nullptr;
   a.tab = s->d_tab;
-  a.part = s->d_part; a.gidx = s->d_gidx; a.order = s->d_order; a.bstart = s->d_bstart;
+  a.part = s->d_part; a.gidx = s->d_gidx; a.order = s->d_order; a.bstart = s->d_bstart; a.bcur = s->d_bcur;
   a.ghist = s->d_ghist;
   a.chunk = s->th_chunk; a.nchunks = s->th_nchunks;
   a.slot0 = s->th_slot0; a.nslots = s->th_nslots;

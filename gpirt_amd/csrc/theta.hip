@@ -244,20 +244,30 @@ __global__ __launch_bounds__(1024) void theta_bucket_kernel(ThetaArgs a, int cou
     lane_tot[tid] = incl;
   }
   __syncthreads();
-  for (int g = tid; g < G; g += 1024) a.bstart[g] = hist[g];
+  for (int g = tid; g < G; g += 1024) { a.bstart[g] = hist[g]; a.bcur[g] = hist[g]; }
   if (tid == 0) a.bstart[G] = lane_tot[63];
+  (void)n;
+}
+
+// Every entry to a place in its bucket (the order inside a bucket is immaterial), one thread an entry over the
+// whole chip; inside the single workgroup of the scan above this took three quarters of its 20 us.  The entries of a
+// workgroup are counted per bucket in LDS first, so that a bucket's global cursor is advanced once per workgroup, not
+// once per entry: a hundred and more entries share the buckets around the centre of the prior, and atomics on one
+// address follow each other at the latency of the L2.
+__global__ __launch_bounds__(1024) void theta_scatter_kernel(ThetaArgs a, int count) {
+  __shared__ int cnt[THETA_BUCKET_MAX_G];
+  __shared__ int base[THETA_BUCKET_MAX_G];
+  const int tid = threadIdx.x, v = blockIdx.x * 1024 + tid;
+  for (int g = tid; g < THETA_BUCKET_MAX_G; g += 1024) cnt[g] = 0;
   __syncthreads();
-  constexpr int B = 10;    // entries per thread and trip: their loads are issued together
-  for (int base = tid; base < n; base += 1024 * B) {
-    int gs[B];
-#pragma unroll
-    for (int b = 0; b < B; ++b) gs[b] = a.gidx[min(base + 1024 * b, n - 1)];
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-      const int i = base + 1024 * b;
-      if (i < n && gs[b] >= 0) a.order[atomicAdd(&hist[gs[b]], 1)] = i;   // order inside a bucket is immaterial
-    }
-  }
+  const int g = v < count ? a.gidx[v] : -1;
+  int rank = 0;
+  if (g >= 0) rank = atomicAdd(&cnt[g], 1);
+  __syncthreads();
+  for (int b = tid; b < a.G; b += 1024)
+    if (cnt[b] > 0) base[b] = atomicAdd(&a.bcur[b], cnt[b]);
+  __syncthreads();
+  if (g >= 0) a.order[base[g] + rank] = v;
 }
 
 constexpr int BUCKET_CHUNK_MAX = 1024;   // items per chunk: at most 16 per lane, held in registers
@@ -423,6 +433,8 @@ int launch_theta_eval_bucketed(hipStream_t st, const ThetaArgs &a, int initial) 
   if (a.H != 1 || a.G > THETA_BUCKET_MAX_G || !a.tab || !a.part) return GPIRT_ERR_BAD_ARG;
   const int count = initial ? a.n : THETA_SPEC * a.n;
   hipLaunchKernelGGL(theta_bucket_kernel, dim3(1), dim3(1024), 0, st, a, count);
+  GP_HIP(hipGetLastError());
+  hipLaunchKernelGGL(theta_scatter_kernel, dim3((count + 1023) / 1024), dim3(1024), 0, st, a, count);
   GP_HIP(hipGetLastError());
   const size_t lane_lds = sizeof(double) * (size_t)(a.C + 1) * a.chunk;
   if (a.yTl && a.chunk == 1024 && a.ML % 1024 == 0)
