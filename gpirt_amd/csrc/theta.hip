@@ -471,88 +471,125 @@ int launch_theta_eval(hipStream_t st, const ThetaArgs &a, int initial, bool wide
 // q0, q0+1, ... in order and stops at the first accepted one.  A respondent that is still
 // active then gets its next THETA_SPEC proposals, each drawn from the bracket that the
 // rejection of the one before would leave (:92-100).
-__device__ inline void theta_decide_one(const ThetaArgs &a, int q0, int round, int i, unsigned long long &seen) {
+// Four lanes to a respondent, lane k for proposal k: the log-likelihoods are read, the uniforms drawn and the new
+// states formed (a sine and a cosine each) side by side; what is sequential -- which proposal is the first to stop
+// the chain, how the bracket shrinks from one proposal to the next -- is a ballot and a walk over four shuffled
+// numbers that every lane of the four makes for itself.  The arithmetic of a proposal is the one-thread form's,
+// operation for operation.  (One thread per respondent: 15.8 us a round, the chain of four Philox blocks, four
+// sincos and the dependent loads in between.)
+__global__ void theta_decide_kernel(ThetaArgs a, int q0, int round) {
+  static_assert(THETA_SPEC == 4, "four lanes to a respondent");
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 2, k = t & 3;
+  const int qb = (threadIdx.x & 63) & ~3;                   // first lane of this respondent's four
   const int H = a.H, n = a.n;
   const int64_t V = (int64_t)THETA_SPEC * n;
-  auto value = [&](int k) -> double {
-    const int64_t v = (int64_t)k * n + i;
+  const bool live = i < n;                                  // the same for the four lanes
+  unsigned long long seen = 0;
+  auto value = [&](int kk) -> double {                      // the sum a decision reads
+    const int64_t v = (int64_t)kk * n + i;
     double ll = 0.0;
     if (!a.from_parts) ll = a.buf[v];
     else                     // bucketed evaluation: the chunk partials, summed in fixed order
       for (int ch = 0; ch < a.nslots; ++ch) ll += a.part[V * ch + v];
-    // every sum a decision reads, by its bits and its place (a.ll_seen only)
-    seen += (unsigned long long)__double_as_longlong(ll) * (unsigned long long)(2 * v + 1);
     return ll;
   };
-  auto finish = [&](int q, bool capped) {
-    a.done[i] = 0;
-    atomicMax(&a.remaining[a.R + 3], q);
-    if (capped) atomicAdd(&a.counters[1], 1ull);
-    if (a.part)
-      for (int k = 0; k < THETA_SPEC; ++k) a.gidx[(int64_t)k * n + i] = -1;
+  // every sum a decision reads, by its bits and its place (a.ll_seen only)
+  auto note = [&](int kk, double ll) {
+    const int64_t v = (int64_t)kk * n + i;
+    seen += (unsigned long long)__double_as_longlong(ll) * (unsigned long long)(2 * v + 1);
   };
-  double lo, hi, first_phi = 0.0;
-  int q;                                       // number of the next proposal
+  double lo = 0.0, hi = 0.0, first_phi = 0.0;
+  int q = 0;                                                // number of the next proposal
+  bool gen = false;                                         // this respondent gets new proposals
   if (q0 == 0) {
-    a.hh[i] = log(rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, 0)) + value(0);
-    first_phi = rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, 1) * kTwoPi;
-    lo = first_phi - kTwoPi;
-    hi = first_phi;
-    q = 1;
-  } else {
-    const int nv = a.done[i];
-    if (nv == 0) return;
-    const double hh = a.hh[i];
-    lo = a.pmin[i];
-    hi = a.pmax[i];
-    for (int k = 0; k < nv; ++k) {
-      const int qk = q0 + k;
-      if (value(k) > hh) {
-        for (int h = 0; h < H; ++h)
-          a.theta[i + (int64_t)n * h] = a.prop[(int64_t)k * n + i + V * h] + prior_mean(a.tpm, i, h);
-        finish(qk, false);
-        return;
+    if (live) {
+      const double ll = value(0);
+      if (k == 0) {
+        note(0, ll);
+        a.hh[i] = log(rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, 0)) + ll;
       }
-      const double phi = a.phi[(int64_t)k * n + i];
-      if (phi > 0.0) hi = phi;
-      else if (phi < 0.0) lo = phi;
-      else { finish(qk, true); return; }
-      if (qk >= a.R) { finish(qk, true); return; }
+      first_phi = rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, 1) * kTwoPi;
+      lo = first_phi - kTwoPi;
+      hi = first_phi;
+      q = 1;
+      gen = true;
     }
-    q = q0 + nv;             // all rejected: nv = THETA_SPEC here (a shorter chain ends above)
+  } else {
+    const int nv = live ? a.done[i] : 0;
+    const int qk = q0 + k;
+    double ll = 0.0, phik = 0.0;
+    bool acc = false;
+    if (k < nv) {
+      ll = value(k);
+      acc = ll > a.hh[i];
+      phik = a.phi[(int64_t)k * n + i];
+    }
+    // proposal k ends the chain if it is accepted, if its angle is exactly zero, or if it was the last one allowed
+    const bool stop = k < nv && (acc || phik == 0.0 || qk >= a.R);
+    const unsigned four = (unsigned)(__ballot(stop) >> qb) & 0xFu;
+    const int first = four ? __ffs(four) - 1 : THETA_SPEC;
+    if (k < nv && k <= first) note(k, ll);                  // the sums read up to the one that stopped the chain
+    const double p0 = __shfl(phik, qb, 64), p1 = __shfl(phik, qb + 1, 64), p2 = __shfl(phik, qb + 2, 64),
+                 p3 = __shfl(phik, qb + 3, 64);
+    if (first < THETA_SPEC) {
+      if (k == first) {
+        if (acc)
+          for (int h = 0; h < H; ++h)
+            a.theta[i + (int64_t)n * h] = a.prop[(int64_t)k * n + i + V * h] + prior_mean(a.tpm, i, h);
+        a.done[i] = 0;
+        atomicMax(&a.remaining[a.R + 3], qk);
+        if (!acc) atomicAdd(&a.counters[1], 1ull);
+      }
+      if (a.part) a.gidx[(int64_t)k * n + i] = -1;
+    } else if (nv > 0) {
+      // all rejected: the bracket after their angles, in order
+      lo = a.pmin[i];
+      hi = a.pmax[i];
+      const double ps[THETA_SPEC] = {p0, p1, p2, p3};
+#pragma unroll
+      for (int kk = 0; kk < THETA_SPEC; ++kk)
+        if (kk < nv) {
+          if (ps[kk] > 0.0) hi = ps[kk];
+          else if (ps[kk] < 0.0) lo = ps[kk];
+        }
+      q = q0 + nv;           // nv = THETA_SPEC here (a shorter chain ends above)
+      gen = true;
+    }
   }
-  a.pmin[i] = lo;
-  a.pmax[i] = hi;
-  int cnt = 0;
-  double phi = 0.0;
-  for (int k = 0; k < THETA_SPEC; ++k) {
+  if (gen) {
+    if (k == 0) { a.pmin[i] = lo; a.pmax[i] = hi; }
     const int qk = q + k;
-    if (k > 0) {             // as if proposal qk - 1 had been rejected
-      if (phi > 0.0) hi = phi;
-      else if (phi < 0.0) lo = phi;
-      else break;
-      if (qk - 1 >= a.R) break;
+    const double u = qk == 1 ? 0.0 : rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, (uint32_t)qk);
+    const double us[THETA_SPEC] = {__shfl(u, qb, 64), __shfl(u, qb + 1, 64), __shfl(u, qb + 2, 64), __shfl(u, qb + 3, 64)};
+    int cnt = 0;
+    double phi = 0.0, mine = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < THETA_SPEC; ++kk) {
+      if (kk > 0) {            // as if proposal q + kk - 1 had been rejected
+        if (phi > 0.0) hi = phi;
+        else if (phi < 0.0) lo = phi;
+        else break;
+        if (q + kk - 1 >= a.R) break;
+      }
+      phi = q + kk == 1 ? first_phi : us[kk] * (hi - lo) + lo;
+      if (kk == k) mine = phi;
+      ++cnt;
     }
-    phi = qk == 1 ? first_phi
-                  : rng_uniform_at(a.seed, TAG_T_U, a.sweep, (uint32_t)i, (uint32_t)qk) * (hi - lo) + lo;
     const int64_t v = (int64_t)k * n + i;
-    a.phi[v] = phi;
-    double s, c;
-    sincos(phi, &s, &c);
-    for (int h = 0; h < H; ++h) a.prop[v + V * h] = a.xc[i + (int64_t)n * h] * c + a.nu[i + (int64_t)n * h] * s;
-    if (a.part) bucket_note(a, (int)v, a.prop[v] + prior_mean(a.tpm, i, 0));
-    ++cnt;
+    if (k < cnt) {
+      a.phi[v] = mine;
+      double sn, cs;
+      sincos(mine, &sn, &cs);
+      for (int h = 0; h < H; ++h) a.prop[v + V * h] = a.xc[i + (int64_t)n * h] * cs + a.nu[i + (int64_t)n * h] * sn;
+      if (a.part) bucket_note(a, (int)v, a.prop[v] + prior_mean(a.tpm, i, 0));
+    } else if (a.part) {
+      a.gidx[v] = -1;
+    }
+    if (k == 0) {
+      a.done[i] = cnt;
+      atomicAdd(&a.remaining[round], 1);
+    }
   }
-  if (a.part)
-    for (int k = cnt; k < THETA_SPEC; ++k) a.gidx[(int64_t)k * n + i] = -1;
-  a.done[i] = cnt;
-  atomicAdd(&a.remaining[round], 1);
-}
-
-__global__ void theta_decide_kernel(ThetaArgs a, int q0, int round) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long seen = 0;
-  if (i < a.n) theta_decide_one(a, q0, round, i, seen);
   if (a.ll_seen) {           // one wrapping sum per wave, then one atomic
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) seen += __shfl_xor(seen, off, 64);
@@ -561,7 +598,7 @@ __global__ void theta_decide_kernel(ThetaArgs a, int q0, int round) {
 }
 
 int launch_theta_decide(hipStream_t st, const ThetaArgs &a, int q0, int round) {
-  hipLaunchKernelGGL(theta_decide_kernel, dim3((a.n + 127) / 128), dim3(128), 0, st, a, q0, round);
+  hipLaunchKernelGGL(theta_decide_kernel, dim3((THETA_SPEC * a.n + 127) / 128), dim3(128), 0, st, a, q0, round);
   GP_HIP(hipGetLastError());
   return GPIRT_OK;
 }
