@@ -471,7 +471,7 @@ def main():
                 "ms_per_step": upd_ms / args.steps if args.steps else 0.0,
                 "algorithmic_bytes_per_launch": ((upd_fl / upd_n) / (2.0 * 128 * 128 * 512) * (2 * 128 * 128 * 8)
                                                  if upd_n else 0.0),
-                "traffic": upd_pmc["hbm_bytes_per_launch"] if upd_pmc else None,
+                "traffic": upd_pmc.get("hbm_bytes_per_launch") if upd_pmc else None,
                 "traffic_note": "mean HBM bytes per launch of this kernel from profiles/" + PMC_FILE +
                                 " (rocprofv3 --pmc, 2 x FETCH_SIZE + WRITE_SIZE); algorithmic = read + write of "
                                 "each lower tile of the trailing matrix once (the 512-wide panel is re-read from cache)",
@@ -481,7 +481,7 @@ def main():
                         "flop_per_launch": fl_launch, "ms_per_launch": nu_ms,
                         "algorithmic_bytes_per_launch": 8.0 * ((float(n) * n - float(r0) * r0) / 2 - float(k0) * (n - r0)
                                                                + float(n - k0) * mloc + (2.0 if k0 else 1.0) * (n - r0) * mloc),
-                        "traffic": nu_pmc["hbm_bytes_per_launch"] if nu_pmc else None,
+                        "traffic": nu_pmc.get("hbm_bytes_per_launch") if nu_pmc else None,
                         "note": ("this launch shares the chip with the chunk of rows that the second stream has not "
                                  "finished when the factorisation ends (224 workgroups on 224 CUs for about half of "
                                  "the launch's span in the kernel trace): `achieved` counts this launch's flop only, "
@@ -503,7 +503,7 @@ def main():
                 "ms_per_launch": nu_alone_ms, "flop_per_launch": float(n) * n * mloc,
                 "achieved": whole, "frac": whole / FP64_MFMA_PEAK_TFLOPS,
                 "algorithmic_bytes_per_launch": 8.0 * (float(n) * n / 2 + 2.0 * n * mloc),
-                "traffic": wp["hbm_bytes_per_launch"] if wp else None}
+                "traffic": wp.get("hbm_bytes_per_launch") if wp else None}
         if potrf_alone_ms:
             ch = n ** 3 / 3.0 / (potrf_alone_ms * 1e-3) / 1e12
             out["roofline"]["cholesky_phase_alone"] = {
@@ -520,7 +520,7 @@ def main():
         lik = {}
         for label in ("ess_f", "ess_param", "theta_eval_bucket", "theta_table"):
             k = pmc_kernel(rec, label, n, m, world)
-            if k:
+            if k and "hbm_bytes_per_launch" in k and "hbm_GBps_profiled" in k:
                 lik[label] = {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"],
                               "hbm_GBps_under_the_profiler": k["hbm_GBps_profiled"],
                               "frac_of_hbm_peak": k["hbm_GBps_profiled"] / HBM_PEAK_GBS,
