@@ -162,60 +162,50 @@ int launch_theta_table(hipStream_t st, const ThetaArgs &a) {
 
 template <int WPR>
 __global__ __launch_bounds__(256) void theta_eval_table_kernel(ThetaArgs a, int initial) {
-  __shared__ double red[2][4];
+  __shared__ double red[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  // WPR = 4, a round of proposals: one workgroup per respondent, which goes through the respondent's
-  // live proposals one after the other (a workgroup per entry was 4n workgroups, most of them returning
-  // at once, and the launch took as long as handing them out)
-  const bool per_respondent = WPR == 4 && !initial;
-  const int first = WPR == 1 ? blockIdx.x * 4 + w : blockIdx.x;      // entry k*n + i
+  const int v = WPR == 1 ? blockIdx.x * 4 + w : blockIdx.x;      // entry k*n + i
   const int count = initial ? a.n : THETA_SPEC * a.n;
-  if (first >= (per_respondent ? a.n : count)) return;
-  const int i = first % a.n;
+  if (v >= count) return;
+  const int i = v % a.n;
   const int64_t V = (int64_t)THETA_SPEC * a.n;
-  const int live = initial ? 1 : a.done[i];
+  if (!initial && v / a.n >= a.done[i]) {    // uniform over the workgroup when WPR = 4
+    if (lane == 0 && (WPR == 1 || w == 0)) a.buf[v] = 0.0;
+    return;
+  }
   const int H = a.H, n = a.n, mloc = a.mloc, ML = a.ML;
   const int64_t U_pad = a.U_pad;
   const int jfirst = WPR == 1 ? lane : lane + 64 * w, jstep = 64 * WPR;
-  const int trips = per_respondent ? THETA_SPEC : 1;
-  for (int k = 0; k < trips; ++k) {
-    const int v = per_respondent ? k * n + i : first;
-    if (!initial && v / n >= live) {           // uniform over the workgroup when WPR = 4
-      if (lane == 0 && (WPR == 1 || w == 0)) a.buf[v] = 0.0;
-      continue;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (int h = 0; h < H; ++h) {
+    double th = initial ? a.theta[i + (int64_t)n * h] : a.prop[v + V * h] + prior_mean(a.tpm, i, h);
+    const int g = grid_index(th, a.grid_lo, a.grid_step, a.G, a.index_truncate);
+    const int p = a.constant_irf ? 0 : h;
+    const double *row = a.tab + U_pad * a.C * g + (int64_t)ML * p;
+    const int8_t *yr = a.yT + (int64_t)ML * H * i + (int64_t)ML * h;
+    int jl = jfirst;
+    for (; jl + 3 * jstep < mloc; jl += 4 * jstep) {      // four independent gathers in flight
+      const int y0 = yr[jl], y1 = yr[jl + jstep], y2 = yr[jl + 2 * jstep], y3 = yr[jl + 3 * jstep];
+      const double v0 = row[jl + U_pad * (max(y0, 1) - 1)];
+      const double v1 = row[jl + jstep + U_pad * (max(y1, 1) - 1)];
+      const double v2 = row[jl + 2 * jstep + U_pad * (max(y2, 1) - 1)];
+      const double v3 = row[jl + 3 * jstep + U_pad * (max(y3, 1) - 1)];
+      s0 += y0 > 0 ? v0 : 0.0; s1 += y1 > 0 ? v1 : 0.0;
+      s2 += y2 > 0 ? v2 : 0.0; s3 += y3 > 0 ? v3 : 0.0;
     }
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int h = 0; h < H; ++h) {
-      double th = initial ? a.theta[i + (int64_t)n * h] : a.prop[v + V * h] + prior_mean(a.tpm, i, h);
-      const int g = grid_index(th, a.grid_lo, a.grid_step, a.G, a.index_truncate);
-      const int p = a.constant_irf ? 0 : h;
-      const double *row = a.tab + U_pad * a.C * g + (int64_t)ML * p;
-      const int8_t *yr = a.yT + (int64_t)ML * H * i + (int64_t)ML * h;
-      int jl = jfirst;
-      for (; jl + 3 * jstep < mloc; jl += 4 * jstep) {      // four independent gathers in flight
-        const int y0 = yr[jl], y1 = yr[jl + jstep], y2 = yr[jl + 2 * jstep], y3 = yr[jl + 3 * jstep];
-        const double v0 = row[jl + U_pad * (max(y0, 1) - 1)];
-        const double v1 = row[jl + jstep + U_pad * (max(y1, 1) - 1)];
-        const double v2 = row[jl + 2 * jstep + U_pad * (max(y2, 1) - 1)];
-        const double v3 = row[jl + 3 * jstep + U_pad * (max(y3, 1) - 1)];
-        s0 += y0 > 0 ? v0 : 0.0; s1 += y1 > 0 ? v1 : 0.0;
-        s2 += y2 > 0 ? v2 : 0.0; s3 += y3 > 0 ? v3 : 0.0;
-      }
-      for (; jl < mloc; jl += jstep) {
-        const int y0 = yr[jl];
-        const double v0 = row[jl + U_pad * (max(y0, 1) - 1)];
-        s0 += y0 > 0 ? v0 : 0.0;
-      }
+    for (; jl < mloc; jl += jstep) {
+      const int y0 = yr[jl];
+      const double v0 = row[jl + U_pad * (max(y0, 1) - 1)];
+      s0 += y0 > 0 ? v0 : 0.0;
     }
-    const double acc = wave_sum((s0 + s1) + (s2 + s3));
-    if (WPR == 1) {
-      if (lane == 0) a.buf[v] = acc;
-    } else {
-      double *r = red[k & 1];                  // two sets: a trip's sums are read while the next trip's are written
-      if (lane == 0) r[w] = acc;
-      __syncthreads();
-      if (threadIdx.x == 0) a.buf[v] = (r[0] + r[1]) + (r[2] + r[3]);
-    }
+  }
+  const double acc = wave_sum((s0 + s1) + (s2 + s3));
+  if (WPR == 1) {
+    if (lane == 0) a.buf[v] = acc;
+  } else {
+    if (lane == 0) red[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) a.buf[v] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
@@ -464,8 +454,7 @@ int launch_theta_eval_bucketed(hipStream_t st, const ThetaArgs &a, int initial) 
 
 int launch_theta_eval(hipStream_t st, const ThetaArgs &a, int initial, bool wide) {
   const int count = initial ? a.n : THETA_SPEC * a.n;
-  // a round of proposals, table variant, wide: a workgroup per respondent rather than per entry
-  const dim3 grid(wide ? (initial || !a.tab ? count : a.n) : (count + 3) / 4);
+  const dim3 grid(wide ? count : (count + 3) / 4);
   if (a.tab) {
     if (wide) hipLaunchKernelGGL(theta_eval_table_kernel<4>, grid, dim3(256), 0, st, a, initial);
     else hipLaunchKernelGGL(theta_eval_table_kernel<1>, grid, dim3(256), 0, st, a, initial);
