@@ -368,6 +368,23 @@ def main():
     lookahead = s.factor_lookahead()
     k0 = min(512 * s.nu_tail_panels(), r0)
     elapsed = max_over_ranks(elapsed)
+    # With the slice steps in two shares of the units (the second on a stream of its own, the f* step beside its
+    # parameter update) the marks of "ess_f", "ess_param" and "fstar" on the main stream no longer bracket one
+    # step each: the same sweeps again with one launch per step give each step's own time, for the rates below.
+    shares = s.slice_second_share()
+    alone = None
+    if shares > 0:
+        kept = os.environ.get("GPIRT_SLICE_SHARES")
+        os.environ["GPIRT_SLICE_SHARES"] = "0"
+        a0, e0 = s.phase_times(), s.diagnostics()
+        s.sweep(args.steps)
+        a1, e1 = s.phase_times(), s.diagnostics()
+        alone_evals = {k: (e1[k] - e0[k]) / args.steps for k in ("ess_f_rounds", "ess_param_rounds")}
+        alone = {k: (a1[k][0] - a0[k][0]) / args.steps for k in a1}
+        if kept is None:
+            del os.environ["GPIRT_SLICE_SHARES"]
+        else:
+            os.environ["GPIRT_SLICE_SHARES"] = kept
 
     # The same sweep with the prior factor kept in generator form (GPIRT_GENERATOR_PRIOR): the
     # headline above is the dense formulation (n x n Cholesky, nu = L*Z as one triangular
@@ -488,7 +505,8 @@ def main():
                                  "the two together run at ~0.8 of peak over the span (DESIGN.md, section 3)") if r0 > 0 else None},
                 },
             },
-            "substeps": substeps(n, mloc, C, cfg.n_grid, phases, evals, r0, lookahead, k0),
+            "substeps": substeps(n, mloc, C, cfg.n_grid, dict(phases, **{k: alone[k] for k in ("ess_f", "ess_param", "fstar")})
+                                 if alone else phases, dict(evals, **alone_evals) if alone else evals, r0, lookahead, k0),
             "phases_ms": phases,
             "launch_marks_per_step": launches,
             "dense_tflops": (fl["potrf"] + fl["nu"]) / (dense_ms * 1e-3) / 1e12 if dense_ms > 0 else 0.0,
@@ -531,6 +549,17 @@ def main():
                 "source": "profiles/" + PMC_FILE + " (rocprofv3 --pmc passes of this benchmark; durations and "
                           "rates are those under the profiler, which serialises kernels and lowers the clock)",
                 "bound": "FP64 VALU issue and LDS gathers of the Mills-ratio table, not HBM: see valu_issue_cycles_share", "kernels": lik}
+        if alone:
+            out["slice_schedule"] = {
+                "second_share_units": shares,
+                "phases_ms_one_launch_per_step": {k: alone[k] for k in ("ess_f", "ess_param", "fstar")},
+                "span_ms": phases["ess_f"] + phases["ess_param"] + phases["fstar"],
+                "likelihood_evals_per_step_in_those_sweeps": alone_evals,
+                "note": "the slice updates of f and of (beta, thresholds) run in two shares of the units, the second "
+                        "on a low-priority stream, and the f* step runs beside the second share's parameter update: "
+                        "in `phases_ms` the marks of ess_f / ess_param / fstar overlap (their sum is the span); "
+                        "`substeps` quotes these three from %d more sweeps with one launch per step "
+                        "(GPIRT_SLICE_SHARES=0), same chain bit for bit" % args.steps}
         if variant is not None:
             out["variants"] = {"generator_prior": variant}
         if world == 1 and not args.no_cpu_baseline:

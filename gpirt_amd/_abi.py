@@ -99,6 +99,7 @@ class GpirtOutputs(C.Structure):
         ("nu_rows_beside_factor", C.c_int32),
         ("factor_lookahead", C.c_int32),
         ("nu_tail_panels", C.c_int32),
+        ("slice_second_share", C.c_int32),
         ("seconds_total", C.c_double),
     ]
 

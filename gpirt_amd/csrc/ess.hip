@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64 * block_waves(WPU)) void ess_f_kernel(EssFArgs a
   int cp = 0;   // checks so far: consecutive checks alternate between the two exchange slots
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   // the unit is the same for every lane of a wave: say so, and its columns' addresses stay scalar
-  const int u = WPU == 1 ? __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + w) : blockIdx.x;
+  const int u = WPU == 1 ? __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + w) : blockIdx.x + a.u0;
   if (u >= a.U_pad || u % a.ML >= a.mloc) return;    // uniform over the workgroup when WPU = 4
   double *sb = sbb[WPU == 1 ? w : 0];
   double2 *sp = spp[WPU == 1 ? w : 0];
@@ -346,7 +346,7 @@ int launch_ess_f(hipStream_t st, const EssFArgs &a) {
   if (a.wide8 && a.Np >= WIDE_UNIT_ROWS)
     hipLaunchKernelGGL(ess_f_kernel<8>, dim3(a.U_pad), dim3(64 * 8), 0, st, a);
   else if (a.Np >= WIDE_UNIT_ROWS)
-    hipLaunchKernelGGL(ess_f_kernel<4>, dim3(a.U_pad), dim3(64 * WPB), 0, st, a);
+    hipLaunchKernelGGL(ess_f_kernel<4>, dim3(a.ucount ? a.ucount : a.U_pad), dim3(64 * WPB), 0, st, a);
   else
     hipLaunchKernelGGL(ess_f_kernel<1>, dim3((a.U_pad + WPB - 1) / WPB), dim3(64 * WPB), 0, st, a);
   GP_HIP(hipGetLastError());
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64 * block_waves(WPU)) void ess_param_kernel(EssPar
   __syncthreads();
   int cp = 0;   // checks so far: consecutive checks alternate between the two exchange slots
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int u = WPU == 1 ? __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + w) : blockIdx.x;
+  const int u = WPU == 1 ? __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + w) : blockIdx.x + a.u0;
   if (u >= a.U_pad || u % a.ML >= a.mloc) return;    // uniform over the workgroup when WPU = 4
   double *sb = sbb[WPU == 1 ? w : 0];
   double2 *sp = spp[WPU == 1 ? w : 0];
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64 * block_waves(WPU)) void ess_param_kernel(EssPar
 
 int launch_ess_param(hipStream_t st, const EssParamArgs &a) {
   if (a.Np >= WIDE_UNIT_ROWS)
-    hipLaunchKernelGGL(ess_param_kernel<4>, dim3(a.U_pad), dim3(64 * WPB), 0, st, a);
+    hipLaunchKernelGGL(ess_param_kernel<4>, dim3(a.ucount ? a.ucount : a.U_pad), dim3(64 * WPB), 0, st, a);
   else
     hipLaunchKernelGGL(ess_param_kernel<1>, dim3((a.U_pad + WPB - 1) / WPB), dim3(64 * WPB), 0, st, a);
   GP_HIP(hipGetLastError());

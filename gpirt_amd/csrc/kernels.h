@@ -30,6 +30,7 @@ struct EssFArgs {
   int32_t *rounds; double *ll;               // per-unit outputs (optional)
   unsigned long long *counters;              // [0] likelihood evaluations, [1] capped updates
   int wide8;                                 // eight waves per unit instead of four (few units of many rows)
+  int u0, ucount;                            // a launch of the units u0 .. u0 + ucount - 1 (ucount = 0: all)
 };
 int launch_ess_f(hipStream_t st, const EssFArgs &a);
 
@@ -50,6 +51,7 @@ struct EssParamArgs {
   double *ll;
   const double *ll_in;   // log-likelihood of the current state if the caller has it (else null)
   unsigned long long *counters;
+  int u0, ucount;                            // as in EssFArgs
 };
 int launch_ess_param(hipStream_t st, const EssParamArgs &a);
 

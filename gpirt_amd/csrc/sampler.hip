@@ -185,6 +185,14 @@ struct gpirt_sampler {
   // times the factor + nu span of every combination it may use in its first sweeps (two sweeps
   // each, the second one timed) and keeps the fastest.
   hipStream_t st2;
+  // The slice steps in two shares of the units: the second share's kernels go to a stream of lower priority, so that
+  // its workgroups fill the chip while the first share's last, longest units finish (a launch of these kernels ends
+  // with ~0.2 ms in which a few units run on a mostly empty chip), and the f* step, which needs f only, runs beside
+  // the second share's parameter update.  share_units: units in the second share (0: one launch per step);
+  // share_now: what the sweep under way uses until its shares are joined; share_last: what the last sweep used.
+  hipStream_t st_lo = nullptr;
+  hipEvent_t ev_share[3] = {nullptr, nullptr, nullptr};   // nu ready / second share's f done / its parameters done
+  int share_units = 0, share_now = 0, share_last = 0;
   int lookahead;       // look-ahead may be used (1), is forced (2)
   int nu_lone;         // the chunks of nu beside the factorisation run one workgroup to a CU
   std::vector<hipEvent_t> ev_ahead;
@@ -205,6 +213,16 @@ struct gpirt_sampler {
   float sched_ms[4];   // measured span per candidate (the shorter of its two timed sweeps)
   int span_last[2];    // that span was the candidate's last timed sweep
 };
+
+// units in the second share of the slice steps: three eighths from 2048 units on, or what GPIRT_SLICE_SHARES says
+static void choose_slice_shares(gpirt_sampler *s) {
+  s->share_units = 0;
+  if (!s->st_lo) return;
+  const char *e = getenv("GPIRT_SLICE_SHARES");
+  int k = s->mloc * s->P >= 2048 ? (3 * s->U_pad) / 8 : 0;
+  if (e) k = atoi(e);
+  s->share_units = std::max(0, std::min(k, s->U_pad - 1));
+}
 
 static void sampler_free(gpirt_sampler *s) {
   if (!s) return;
@@ -229,6 +247,8 @@ static void sampler_free(gpirt_sampler *s) {
   if (s->ev_pref) (void)hipEventDestroy(s->ev_pref);
   if (s->ev_tail) (void)hipEventDestroy(s->ev_tail);
   for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) if (s->ev_span[a][b]) (void)hipEventDestroy(s->ev_span[a][b]);
+  for (hipEvent_t e : s->ev_share) if (e) (void)hipEventDestroy(e);
+  if (s->st_lo) (void)hipStreamDestroy(s->st_lo);
   if (s->st2) (void)hipStreamDestroy(s->st2);
   if (s->st) (void)hipStreamDestroy(s->st);
   delete s;
@@ -691,6 +711,18 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     }
     if (!ok) { set_error("second stream: creation failed"); return fail(GPIRT_ERR_HIP); }
   }
+  // the slice steps in two shares of the units (see st_lo), from 2048 units of 1024 rows on: n = 10 000, 4096 items,
+  // 60.4 -> 60.85 sweeps/s with 1536 units in the second share; 1024 ... 2048 units and the streams' priorities hardly
+  // matter (60.6-60.85).  GPIRT_SLICE_SHARES=k: k units in the second share (0: one launch per step); read again at
+  // every call that runs sweeps.
+  if (s->Np >= 1024 && mloc * P >= 1024) {
+    int least = 0, greatest = 0;
+    bool ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+              hipStreamCreateWithPriority(&s->st_lo, hipStreamNonBlocking, least) == hipSuccess;
+    for (int i = 0; i < 3 && ok; ++i) ok = hipEventCreateWithFlags(&s->ev_share[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { set_error("low-priority stream: creation failed"); return fail(GPIRT_ERR_HIP); }
+  }
+  choose_slice_shares(s);
   s->span_kind[0] = s->span_kind[1] = -1;
   for (int c = 0; c < 4; ++c) s->sched_ms[c] = 1e30f;
   if (cfg->theta_mode == GPIRT_THETA_GRID) {
@@ -1205,6 +1237,17 @@ static int phase_f(gpirt_sampler *s) {
   // few units of many rows: eight waves a unit.  Not under GPIRT_FIXED_ORDER_SUM, whose promise -- the same bits for
   // every number of ranks -- would not survive an order of summation that depends on a rank's share of the units
   a.wide8 = s->Np >= 4096 && s->mloc * s->P <= 1536 && !(s->cfg.flags & GPIRT_FIXED_ORDER_SUM);
+  s->share_now = s->share_last = a.wide8 ? 0 : s->share_units;
+  if (s->share_now > 0) {
+    GP_HIP(hipEventRecord(s->ev_share[0], s->st));
+    GP_HIP(hipStreamWaitEvent(s->st_lo, s->ev_share[0], 0));
+    a.u0 = 0; a.ucount = s->U_pad - s->share_now;
+    GP_TRY(launch_ess_f(s->st, a));
+    a.u0 = s->U_pad - s->share_now; a.ucount = s->share_now;
+    GP_TRY(launch_ess_f(s->st_lo, a));
+    GP_HIP(hipEventRecord(s->ev_share[1], s->st_lo));
+    return GPIRT_OK;
+  }
   GP_TRY(launch_ess_f(s->st, a));
   return GPIRT_OK;
 }
@@ -1220,6 +1263,14 @@ static int phase_param(gpirt_sampler *s) {
   a.ML = s->ML; a.m = s->m; a.j0 = s->j0; a.R = s->cfg.max_ess_rounds; a.seed = s->seed;
   a.sweep = s->sweep; a.ll = s->d_llu; a.counters = s->d_counters + 2;
   a.ll_in = s->d_llu;       // left by phase_f for the same f, beta and thresholds
+  if (s->share_now > 0) {
+    a.u0 = 0; a.ucount = s->U_pad - s->share_now;
+    GP_TRY(launch_ess_param(s->st, a));
+    a.u0 = s->U_pad - s->share_now; a.ucount = s->share_now;
+    GP_TRY(launch_ess_param(s->st_lo, a));
+    GP_HIP(hipEventRecord(s->ev_share[2], s->st_lo));   // joined behind the f* step
+    return GPIRT_OK;
+  }
   GP_TRY(launch_ess_param(s->st, a));
   return GPIRT_OK;
 }
@@ -1264,9 +1315,19 @@ static int ensure_super_inverses(gpirt_sampler *s) {
   return launch_super_inverses(s->st, s->d_S, s->Np_pad, s->P, s->d_inv, s->d_fwork, true);
 }
 
+static int phase_fstar_body(gpirt_sampler *s);
 static int phase_fstar(gpirt_sampler *s) {
   Range range("gpirt:fstar");
   GP_TRY(mark(s, PH_FSTAR));
+  // with the slice steps in two shares: f of the second share is awaited here (the step reads every unit's f and
+  // parks its partial products in nu), its parameters behind the step, which does not read them
+  if (s->share_now > 0) GP_HIP(hipStreamWaitEvent(s->st, s->ev_share[1], 0));
+  const int rc = phase_fstar_body(s);
+  if (s->share_now > 0) { GP_HIP(hipStreamWaitEvent(s->st, s->ev_share[2], 0)); s->share_now = 0; }
+  return rc;
+}
+
+static int phase_fstar_body(gpirt_sampler *s) {
   // f*^T = F^T S^-1 K(x, xs)   (gp posterior mean, main.m:57-58).  The solve goes to whichever
   // side has fewer columns: W = S^-1 K(x,xs) (G columns, the same on every rank) or
   // alpha = S^-1 F (this rank's units: fewer than G once the items are sharded, and then no
@@ -1528,6 +1589,7 @@ extern "C" {
 int gpirt_sampler_sweep(gpirt_sampler *s, int32_t sweeps) {
   if (!s) { set_error("sampler is NULL"); return GPIRT_ERR_BAD_ARG; }
   GP_HIP(hipSetDevice(s->device));
+  choose_slice_shares(s);
   for (int it = 0; it < sweeps; ++it) {
     Range range("gpirt:sweep");
     GP_TRY(phase_factor(s));   // main.m:67 + the chol of sample_fs.m:2
@@ -1632,6 +1694,7 @@ int gpirt_sampler_diagnostics(gpirt_sampler *s, gpirt_outputs *o) {
   o->nu_rows_beside_factor = s->gen_now ? 0 : s->nu_rows_done;
   o->factor_lookahead = s->gen_now ? 0 : s->la_now;
   o->nu_tail_panels = s->gen_now ? 0 : s->nu_tail_done;
+  o->slice_second_share = s->share_last;
   return GPIRT_OK;
 }
 

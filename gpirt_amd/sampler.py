@@ -122,6 +122,13 @@ class Sampler:
         check(lib().gpirt_sampler_diagnostics(self._h, C.byref(o)))
         return int(o.nu_tail_panels)
 
+    def slice_second_share(self):
+        """Units whose slice updates the last sweep ran as a second share on a stream of their own
+        (0: one launch per step)."""
+        o = _abi.GpirtOutputs()
+        check(lib().gpirt_sampler_diagnostics(self._h, C.byref(o)))
+        return int(o.slice_second_share)
+
     def factor_lookahead(self):
         """True if the last sweep's factorisation ran its trailing updates on the second stream,
         beside the next block columns' steps."""

@@ -171,6 +171,9 @@ typedef struct gpirt_outputs {
                                  on the second stream beside the next block columns' steps */
   int32_t nu_tail_panels;     /* 512-column panels of L whose share of the rows of nu AFTER
                                  nu_rows_beside_factor was added beside the factorisation too */
+  int32_t slice_second_share; /* units (items x IRF groups) whose slice updates the last sweep ran as a
+                                 second share, on a stream of their own beside the first share's
+                                 next step (0: one launch per step); GPIRT_SLICE_SHARES sets it */
   double seconds_total;       /* wall time inside the sweep loop                        */
 } gpirt_outputs;
 

@@ -235,3 +235,33 @@ def test_a_failed_factorisation_is_retried_the_same_way_under_every_schedule(mon
         assert dg == dg0, (flags, forced, ahead)
         for k in ("theta", "f", "beta"):
             assert np.array_equal(base[k], st[k]), (k, flags, forced, ahead)
+
+
+def test_slice_steps_in_two_shares_leave_the_chain_unchanged(monkeypatch):
+    """The slice updates of f and of (beta, thresholds) (elliptical_slice.m:47-102, one update per item) may run
+    in two shares of the units, the second on a stream of its own beside the first share's next step, with the f*
+    step (main.m:57-58, which reads f only) beside the second share's parameter update.  Every unit's update is the
+    same arithmetic on the same random numbers wherever it runs: four sweeps give the same chain bit for bit with
+    one launch per step (GPIRT_SLICE_SHARES=0), with the sampler's own split, with a ragged split and with all
+    units but one in the second share; the same at a size where a unit is a single wave (no split there)."""
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synth import generate
+    for n, m in ((4000, 2304), (600, 2048)):
+        d = generate(n, m, C, seed=7)
+
+        def chain(shares):
+            if shares is None:
+                monkeypatch.delenv("GPIRT_SLICE_SHARES", raising=False)
+            else:
+                monkeypatch.setenv("GPIRT_SLICE_SHARES", str(shares))
+            cfg = _abi.default_config(n=n, m=m, H=1, C=C, seed=8)
+            with Sampler(cfg, d["y"], theta_init=d["theta"]) as s:
+                s.sweep(4)
+                return s.state(fstar=True), s.diagnostics()
+
+        base, dg0 = chain(0)
+        for shares in (None, 777, m - 1, 10 * m):
+            st, dg = chain(shares)
+            assert dg == dg0, (n, shares)
+            for k in ("theta", "f", "beta", "threshold", "fstar"):
+                assert np.array_equal(base[k], st[k]), (k, n, shares)
