@@ -219,7 +219,8 @@ static void choose_slice_shares(gpirt_sampler *s) {
   s->share_units = 0;
   if (!s->st_lo) return;
   const char *e = getenv("GPIRT_SLICE_SHARES");
-  int k = s->mloc * s->P >= 2048 ? (3 * s->U_pad) / 8 : 0;
+  // (one rank only by default: the gain is half a percent, and a schedule with a third stream has not run beside a collective)
+  int k = s->mloc * s->P >= 2048 && s->cfg.world <= 1 ? (3 * s->U_pad) / 8 : 0;
   if (e) k = atoi(e);
   s->share_units = std::max(0, std::min(k, s->U_pad - 1));
 }
