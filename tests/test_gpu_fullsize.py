@@ -265,3 +265,49 @@ def test_slice_steps_in_two_shares_leave_the_chain_unchanged(monkeypatch):
             assert dg == dg0, (n, shares)
             for k in ("theta", "f", "beta", "threshold", "fstar"):
                 assert np.array_equal(base[k], st[k]), (k, n, shares)
+
+
+def test_two_shares_beside_a_host_programs_own_streams(monkeypatch):
+    """The same in a process that holds more HIP streams than the runtime has hardware queues (four by default), of
+    every priority and busy between the sweeps -- a host program's own: the sampler's low-priority stream then
+    shares a queue with others.  Same chain bit for bit as with one launch per step."""
+    import ctypes as ct
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synth import generate
+    hip = ct.CDLL("libamdhip64.so")
+    n, m = 4000, 2304
+    d = generate(n, m, C, seed=7)
+
+    def chain(shares, extra):
+        if shares is None:
+            monkeypatch.delenv("GPIRT_SLICE_SHARES", raising=False)
+        else:
+            monkeypatch.setenv("GPIRT_SLICE_SHARES", str(shares))
+        cfg = _abi.default_config(n=n, m=m, H=1, C=C, seed=8)
+        with Sampler(cfg, d["y"], theta_init=d["theta"]) as s:
+            streams, buf = [], ct.c_void_p()
+            if extra:
+                lo, hi = ct.c_int(), ct.c_int()
+                assert hip.hipDeviceGetStreamPriorityRange(ct.byref(lo), ct.byref(hi)) == 0
+                assert hip.hipMalloc(ct.byref(buf), ct.c_size_t(1 << 20)) == 0
+                for pr in [0] * 6 + [lo.value] * 2 + [hi.value] * 2:
+                    st = ct.c_void_p()
+                    assert hip.hipStreamCreateWithPriority(ct.byref(st), ct.c_uint(1), ct.c_int(pr)) == 0
+                    streams.append(st)
+            for it in range(4):
+                for st in streams:
+                    assert hip.hipMemsetAsync(buf, ct.c_int(it), ct.c_size_t(1 << 20), st) == 0
+                s.sweep(1)
+            shares_used = s.slice_second_share()
+            for st in streams:
+                assert hip.hipStreamSynchronize(st) == 0
+                assert hip.hipStreamDestroy(st) == 0
+            if extra:
+                assert hip.hipFree(buf) == 0
+            return s.state(fstar=True), shares_used
+
+    base, none = chain(0, False)
+    st, used = chain(None, True)
+    assert none == 0 and used == 3 * m // 8
+    for k in ("theta", "f", "beta", "threshold", "fstar"):
+        assert np.array_equal(base[k], st[k]), k
