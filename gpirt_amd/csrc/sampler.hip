@@ -214,13 +214,13 @@ struct gpirt_sampler {
   int span_last[2];    // that span was the candidate's last timed sweep
 };
 
-// units in the second share of the slice steps: three eighths from 2048 units on, or what GPIRT_SLICE_SHARES says
+// units in the second share of the slice steps: three eighths from 1024 units on, or what GPIRT_SLICE_SHARES says
 static void choose_slice_shares(gpirt_sampler *s) {
   s->share_units = 0;
   if (!s->st_lo) return;
   const char *e = getenv("GPIRT_SLICE_SHARES");
   // (one rank only by default: the gain is half a percent, and a schedule with a third stream has not run beside a collective)
-  int k = s->mloc * s->P >= 2048 && s->cfg.world <= 1 ? (3 * s->U_pad) / 8 : 0;
+  int k = s->mloc * s->P >= 1024 && s->cfg.world <= 1 ? (3 * s->U_pad) / 8 : 0;
   if (e) k = atoi(e);
   s->share_units = std::max(0, std::min(k, s->U_pad - 1));
 }
@@ -712,9 +712,9 @@ int gpirt_sampler_create(const gpirt_config *cfg, const int8_t *y, const double 
     }
     if (!ok) { set_error("second stream: creation failed"); return fail(GPIRT_ERR_HIP); }
   }
-  // the slice steps in two shares of the units (see st_lo), from 2048 units of 1024 rows on: n = 10 000, 4096 items,
-  // 60.4 -> 60.85 sweeps/s with 1536 units in the second share; 1024 ... 2048 units and the streams' priorities hardly
-  // matter (60.6-60.85).  GPIRT_SLICE_SHARES=k: k units in the second share (0: one launch per step); read again at
+  // the slice steps in two shares of the units (see st_lo), from 1024 units of 1024 rows on: n = 10 000, 4096 items,
+  // 60.4 -> 60.85 sweeps/s with 1536 units in the second share (1024 ... 2048 units: 60.6-60.85); n = 5000, 2048 items
+  // 218 -> 224; n = 2500, 1024 items 481 -> 494 (there it is the f* step beside the second share that gains).  GPIRT_SLICE_SHARES=k: k units in the second share (0: one launch per step); read again at
   // every call that runs sweeps.
   if (s->Np >= 1024 && mloc * P >= 1024) {
     int least = 0, greatest = 0;

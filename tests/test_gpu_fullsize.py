@@ -274,7 +274,9 @@ def test_two_shares_beside_a_host_programs_own_streams(monkeypatch):
     import ctypes as ct
     from gpirt_amd.sampler import Sampler
     from gpirt_amd.synth import generate
-    hip = ct.CDLL("libamdhip64.so")
+    from gpirt_amd import _lib
+    _lib.lib()                                   # brings the runtime the library itself uses into the process
+    hip = ct.CDLL("libamdhip64.so.7")
     n, m = 4000, 2304
     d = generate(n, m, C, seed=7)
 
